@@ -1,0 +1,52 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def from_bits(b):
+    """uint32 bit patterns -> float32 array."""
+    return np.array(b, dtype=np.uint32).view(np.float32)
+
+
+def to_bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bits_equal(actual, expected_bits, what=""):
+    """Bit-exact f32 comparison; any NaN payload counts as equal to any NaN."""
+    a = np.ascontiguousarray(actual, dtype=np.float32)
+    e = from_bits(expected_bits)
+    assert a.shape == e.shape, "%s: length %s != %s" % (what, a.shape, e.shape)
+    an, en = np.isnan(a), np.isnan(e)
+    assert np.array_equal(an, en), "%s: NaN positions differ" % what
+    ab, eb = a.view(np.uint32), e.view(np.uint32)
+    bad = (ab != eb) & ~an
+    if bad.any():
+        i = int(np.flatnonzero(bad)[0])
+        raise AssertionError("%s: %d of %d samples differ, first at %d: %r (0x%08x) != %r (0x%08x)" % (
+            what, int(bad.sum()), a.size, i, float(a[i]), int(ab[i]), float(e[i]), int(eb[i])))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+    o.build()
+    return o
