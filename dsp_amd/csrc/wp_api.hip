@@ -1,0 +1,710 @@
+// wp_api.hip — the C ABI of libwpdsp.so (include/wpdsp.h): handle management,
+// argument checking and kernel sequencing.  No arithmetic on samples happens on
+// the host: every entry point that produces samples launches the gfx950 kernels
+// and fails with WP_ERR_NO_DEVICE when there is no GPU.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "wp_internal.h"
+
+using namespace wp;
+
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess)                                                             \
+            return fail(WP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+static std::mutex g_mu;
+static int g_ndev = -2;  // -2: not probed
+
+extern "C" int wp_init(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_ndev == -2) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        g_ndev = (e == hipSuccess && n > 0) ? n : -1;
+        if (g_ndev < 0) {
+            (void)hipGetLastError();
+            g_err = std::string("no HIP device: ") + hipGetErrorString(e);
+        }
+    }
+    if (g_ndev < 0) {
+        if (g_err.empty()) g_err = "no HIP device";
+        return WP_ERR_NO_DEVICE;
+    }
+    return g_ndev;
+}
+
+extern "C" const char *wp_last_error(void) { return g_err.c_str(); }
+
+static int need_device()
+{
+    const int n = wp_init();
+    return n < 0 ? n : 0;
+}
+
+// ---------------------------------------------------------------------------
+// integer helpers (host only)
+extern "C" int32_t wp_next_pot(int32_t n)
+{
+    if (n == 0) return 1;
+    int32_t s = n - 1;
+    s |= s >> 1;
+    s |= s >> 2;
+    s |= s >> 4;
+    s |= s >> 8;
+    s |= s >> 16;
+    return s + 1;
+}
+
+extern "C" int32_t wp_fft_length(int64_t L, int64_t M)
+{
+    if (L < 0 || M < 0 || L + M > (1 << 30)) return WP_ERR_FFT_SIZE;
+    return wp_next_pot((int32_t)(L + M));
+}
+
+extern "C" int32_t wp_mix_sl(int64_t rl, double length)
+{
+    const double p = (double)rl * length;
+    if (!isfinite(p)) return 0;
+    double m = fmod(trunc(p), 4294967296.0);
+    if (m < 0) m += 4294967296.0;
+    return (int32_t)(uint32_t)m;
+}
+
+extern "C" int64_t wp_ring_pos(int64_t needle, int64_t key, int64_t length)
+{
+    int64_t pos = needle;
+    if (key != 0) {
+        pos += key;
+        if (pos > length - 1) pos = pos % length;
+        else if (pos < 0 && length > 0) pos = ((pos % length) + length) % length;
+    }
+    return pos;
+}
+
+extern "C" int64_t wp_ring_advance(int64_t needle, int64_t length)
+{
+    needle++;
+    if (needle > length - 1) needle = 0;
+    return needle;
+}
+
+extern "C" int64_t wp_beat_rate(double sample_rate, double bpm)
+{
+    return (int64_t)floor(sample_rate * (60.0 / bpm) + 0.5);
+}
+
+// TypedArray.prototype.subarray(begin, end) index clamping
+static void js_subarray(int64_t n, int64_t begin, int64_t end, int64_t *off, int64_t *len)
+{
+    int64_t b = begin < 0 ? (n + begin > 0 ? n + begin : 0) : (begin < n ? begin : n);
+    int64_t e = end < 0 ? (n + end > 0 ? n + end : 0) : (end < n ? end : n);
+    *off = b;
+    *len = e > b ? e - b : 0;
+}
+
+extern "C" int wp_reverb_view_for(int64_t L, int64_t M, int64_t offset, int64_t len, wp_reverb_view *v)
+{
+    if (!v || L < 0 || M < 0) return fail(WP_ERR_INVALID, "wp_reverb_view_for: bad argument");
+    const int64_t n = L + M;
+    v->curr_len = n;
+    js_subarray(n, offset, offset + len, &v->ret_off, &v->ret_len);
+    const int64_t tail = (n - offset) - len;
+    js_subarray(n, -tail, n, &v->prev_off, &v->prev_len);
+    return WP_OK;
+}
+
+#pragma clang fp contract(off)
+extern "C" int wp_synth_ir(float *out, int64_t M, uint32_t seed)
+{
+    if (!out || M <= 0) return fail(WP_ERR_INVALID, "wp_synth_ir: bad argument");
+    const uint32_t k = seed * 0x9E3779B9u;
+    const float r = (float)(1.0 - 6.907755 / (double)M);
+    float e = 1.0f;
+    double norm = 0.0;
+    for (int64_t i = 0; i < M; i++) {
+        uint32_t h = (uint32_t)i ^ k;
+        h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+        const double nz = ((double)(h >> 8) - 8388608.0) / 8388608.0;
+        out[i] = (float)(nz * (double)e);
+        norm += fabs((double)out[i]);
+        e = (float)((double)e * (double)r);
+    }
+    for (int64_t i = 0; i < M; i++) out[i] = (float)((double)out[i] / norm);
+    return WP_OK;
+}
+
+extern "C" int wp_synth_noise_dev(float *out_dev, int64_t n, uint32_t seed, int64_t start, void *stream)
+{
+    if (int rc = need_device()) return rc;
+    if (!out_dev || n < 0) return fail(WP_ERR_INVALID, "wp_synth_noise_dev: bad argument");
+    HIPCHK(launch_synth_noise(out_dev, n, seed, start, (hipStream_t)stream));
+    return WP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// per-(device, B) twiddle tables
+struct DevTables {
+    c32 *d = nullptr;
+};
+static std::map<std::pair<int, int>, DevTables> g_tables;
+
+static int get_tables(int dev, int B, const c32 **out)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_pair(dev, B);
+    auto it = g_tables.find(key);
+    if (it == g_tables.end()) {
+        const int n = table_total_points(B);
+        std::vector<c32> h(n);
+        const double pi = 3.14159265358979323846;
+        for (int a = 0; a < 256; a++) {
+            h[a] = {(float)cos(2 * pi * a / 256.0), (float)-sin(2 * pi * a / 256.0)};
+            h[256 + a] = {(float)cos(2 * pi * a / B), (float)-sin(2 * pi * a / B)};
+        }
+        for (int b = 0; b < B / 256; b++)
+            h[512 + b] = {(float)cos(2 * pi * b * 256.0 / B), (float)-sin(2 * pi * b * 256.0 / B)};
+        const int wo = table_wsplit_offset(B);
+        for (int q = 0; q < B / 2; q++) h[wo + q] = {(float)cos(pi * q / B), (float)-sin(pi * q / B)};
+        DevTables t;
+        HIPCHK(hipMalloc((void **)&t.d, sizeof(c32) * n));
+        HIPCHK(hipMemcpy(t.d, h.data(), sizeof(c32) * n, hipMemcpyHostToDevice));
+        it = g_tables.emplace(key, t).first;
+    }
+    *out = it->second.d;
+    return WP_OK;
+}
+
+// ---------------------------------------------------------------------------
+struct wp_ir {
+    int dev;
+    int nch;
+    int64_t M, L;
+    int B, P, Pp, PG;
+    float4 *Hp;        // [nch][Pp][B/2]
+    const c32 *tables;
+    int64_t bytes;
+    wp_conv *single;   // lazily built 1-job plan for wp_convolve
+    float *stage_in, *stage_out;
+};
+
+struct wp_conv {
+    wp_ir *ir;
+    int njobs;
+    int T;
+    int tchunk;
+    int32_t *job_irch;  // device
+    c32 *Z, *W;
+    int64_t bytes;
+};
+
+struct wp_reverb {
+    wp_conv *conv;
+    int njobs;
+    int64_t offset;
+    int64_t stride;     // floats between jobs in buf[]
+    float *buf[2];      // ping-pong curr buffers, njobs*stride each
+    int cur;            // buffer holding the latest curr (and the prev view)
+    int64_t prev_off, prev_len;
+    float *stage_in;    // host-API staging, njobs*in_stride
+    int64_t stage_in_len;
+};
+
+static int choose_B(int64_t L, int64_t M)
+{
+    if (const char *e = getenv("WPDSP_B")) {
+        const int b = atoi(e);
+        if (b == 1024 || b == 2048 || b == 4096 || b == 8192) return b;
+    }
+    return (L + M <= 8192) ? 1024 : 4096;
+}
+
+static int choose_PG(int P)
+{
+    if (const char *e = getenv("WPDSP_PG")) {
+        const int g = atoi(e);
+        if (g == 4 || g == 8 || g == 12 || g == 16 || g == 24) return g;
+    }
+    if (P <= 4) return 4;
+    if (P <= 8) return 8;
+    if (P <= 12) return 12;
+    if (P <= 16) return 16;
+    if (P <= 24) return 24;
+    return 12;
+}
+
+static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, int64_t M, int64_t L, hipStream_t s)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        fail(WP_ERR_HIP, "hipGetDevice failed");
+        return nullptr;
+    }
+    wp_ir *ir = new wp_ir();
+    ir->dev = dev;
+    ir->nch = nch;
+    ir->M = M;
+    ir->L = L;
+    ir->B = choose_B(L, M);
+    ir->P = (int)((M + ir->B - 1) / ir->B);
+    ir->PG = choose_PG(ir->P);
+    ir->Pp = ((ir->P + ir->PG - 1) / ir->PG) * ir->PG;
+    ir->single = nullptr;
+    ir->stage_in = ir->stage_out = nullptr;
+    ir->Hp = nullptr;
+    c32 *Zir = nullptr;
+    auto bail = [&](const char *what, hipError_t e) {
+        fail(WP_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+        if (Zir) (void)hipFree(Zir);
+        if (ir->Hp) (void)hipFree(ir->Hp);
+        delete ir;
+        return (wp_ir *)nullptr;
+    };
+    if (get_tables(dev, ir->B, &ir->tables) != WP_OK) {
+        delete ir;
+        return nullptr;
+    }
+    const size_t hbytes = sizeof(float4) * (size_t)nch * ir->Pp * (ir->B / 2);
+    hipError_t e;
+    if ((e = hipMalloc((void **)&ir->Hp, hbytes)) != hipSuccess) return bail("hipMalloc(Hp)", e);
+    if ((e = hipMemsetAsync(ir->Hp, 0, hbytes, s)) != hipSuccess) return bail("hipMemsetAsync", e);
+    if ((e = hipMalloc((void **)&Zir, sizeof(c32) * (size_t)nch * ir->P * ir->B)) != hipSuccess) return bail("hipMalloc(Zir)", e);
+    if ((e = launch_fft_fwd(ir->B, true, ir_dev, ch_stride, M, Zir, ir->P, ir->P, nch, ir->tables, s)) != hipSuccess)
+        return bail("k_fft_fwd(IR)", e);
+    if ((e = launch_hpack(Zir, ir->Hp, ir->tables + table_wsplit_offset(ir->B), ir->B, ir->P, ir->Pp, nch, s)) != hipSuccess)
+        return bail("k_hpack", e);
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail("hipStreamSynchronize", e);
+    (void)hipFree(Zir);
+    ir->bytes = (int64_t)hbytes;
+    return ir;
+}
+
+static int check_ir_args(int nch, int64_t M, int64_t L)
+{
+    if (nch < 1) return fail(WP_ERR_INVALID, "IR needs at least one channel");
+    if (M < 1 || L < 0) return fail(WP_ERR_INVALID, "IR length must be >= 1 and block length >= 0 (M=%lld L=%lld)", (long long)M, (long long)L);
+    if (L + M > (1 << 30)) return fail(WP_ERR_FFT_SIZE, "L+M=%lld exceeds the reference's int32 nextPowerOfTwo range", (long long)(L + M));
+    if (wp_next_pot((int32_t)(L + M)) <= 1) return fail(WP_ERR_FFT_SIZE, "FFT size must be a power of two and bigger than 1");
+    return WP_OK;
+}
+
+extern "C" wp_ir *wp_ir_create_dev(const float *ir_dev, int nch, int64_t ch_stride, int64_t M, int64_t L, void *stream)
+{
+    if (need_device()) return nullptr;
+    if (!ir_dev) {
+        fail(WP_ERR_INVALID, "wp_ir_create_dev: null IR");
+        return nullptr;
+    }
+    if (check_ir_args(nch, M, L)) return nullptr;
+    return ir_create_common(ir_dev, nch, ch_stride, M, L, (hipStream_t)stream);
+}
+
+extern "C" wp_ir *wp_ir_create(const float *const *ir, int nch, int64_t M, int64_t L)
+{
+    if (need_device()) return nullptr;
+    if (!ir) {
+        fail(WP_ERR_INVALID, "wp_ir_create: null IR");
+        return nullptr;
+    }
+    if (check_ir_args(nch, M, L)) return nullptr;
+    float *d = nullptr;
+    hipError_t e = hipMalloc((void **)&d, sizeof(float) * (size_t)nch * M);
+    if (e != hipSuccess) {
+        fail(WP_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    for (int c = 0; c < nch; c++) {
+        e = hipMemcpy(d + (size_t)c * M, ir[c], sizeof(float) * (size_t)M, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            fail(WP_ERR_HIP, "hipMemcpy(IR) failed: %s", hipGetErrorString(e));
+            (void)hipFree(d);
+            return nullptr;
+        }
+    }
+    wp_ir *r = ir_create_common(d, nch, M, M, L, nullptr);
+    (void)hipFree(d);
+    return r;
+}
+
+extern "C" void wp_ir_destroy(wp_ir *ir)
+{
+    if (!ir) return;
+    if (ir->single) wp_conv_destroy(ir->single);
+    if (ir->stage_in) (void)hipFree(ir->stage_in);
+    if (ir->stage_out) (void)hipFree(ir->stage_out);
+    if (ir->Hp) (void)hipFree(ir->Hp);
+    delete ir;
+}
+
+extern "C" int64_t wp_ir_info(const wp_ir *ir, int which)
+{
+    if (!ir) return WP_ERR_INVALID;
+    switch (which) {
+    case 0: return ir->M;
+    case 1: return ir->L;
+    case 2: return ir->nch;
+    case 3: return ir->B;
+    case 4: return ir->P;
+    case 5: return ir->L + ir->M;
+    case 6: return wp_next_pot((int32_t)(ir->L + ir->M));
+    case 7: return ir->bytes;
+    }
+    return WP_ERR_INVALID;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" wp_conv *wp_conv_create(wp_ir *ir, int njobs, const int32_t *job_ch)
+{
+    if (need_device()) return nullptr;
+    if (!ir || njobs < 1 || njobs > 65535 || !job_ch) {
+        fail(WP_ERR_INVALID, "wp_conv_create: bad argument (njobs must be 1..65535)");
+        return nullptr;
+    }
+    for (int j = 0; j < njobs; j++)
+        if (job_ch[j] < 0 || job_ch[j] >= ir->nch) {
+            fail(WP_ERR_INVALID, "wp_conv_create: job %d names IR channel %d of %d", j, job_ch[j], ir->nch);
+            return nullptr;
+        }
+    wp_conv *c = new wp_conv();
+    c->ir = ir;
+    c->njobs = njobs;
+    c->T = (int)((ir->L + ir->M + ir->B - 1) / ir->B);
+    // time chunks: enough threads to fill the chip when there are few jobs
+    {
+        const int64_t per_job = ir->B / 2;
+        int64_t want = (256 * 8 * 64 + per_job * njobs - 1) / (per_job * njobs);
+        int64_t maxchunks = c->T / (2 * ir->PG);
+        if (maxchunks < 1) maxchunks = 1;
+        if (want > maxchunks) want = maxchunks;
+        if (want < 1) want = 1;
+        c->tchunk = (int)((c->T + want - 1) / want);
+    }
+    c->job_irch = nullptr;
+    c->Z = c->W = nullptr;
+    const size_t sbytes = sizeof(c32) * (size_t)njobs * c->T * ir->B;
+    hipError_t e = hipMalloc((void **)&c->job_irch, sizeof(int32_t) * njobs);
+    if (e == hipSuccess) e = hipMemcpy(c->job_irch, job_ch, sizeof(int32_t) * njobs, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->Z, sbytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->W, sbytes);
+    if (e != hipSuccess) {
+        fail(WP_ERR_HIP, "wp_conv_create: allocating %zu bytes of spectra failed: %s", 2 * sbytes, hipGetErrorString(e));
+        wp_conv_destroy(c);
+        return nullptr;
+    }
+    c->bytes = (int64_t)(2 * sbytes + sizeof(int32_t) * njobs);
+    return c;
+}
+
+extern "C" void wp_conv_destroy(wp_conv *c)
+{
+    if (!c) return;
+    if (c->job_irch) (void)hipFree(c->job_irch);
+    if (c->Z) (void)hipFree(c->Z);
+    if (c->W) (void)hipFree(c->W);
+    delete c;
+}
+
+extern "C" int64_t wp_conv_workspace_bytes(const wp_conv *c) { return c ? c->bytes : WP_ERR_INVALID; }
+
+static int check_in_len(const wp_ir *ir, int64_t in_len)
+{
+    const int64_t N = wp_next_pot((int32_t)(ir->L + ir->M));
+    if (in_len < 0) return fail(WP_ERR_INVALID, "negative input length");
+    if (in_len > N) return fail(WP_ERR_RANGE, "offset is out of bounds: input of %lld samples exceeds the FFT length %lld", (long long)in_len, (long long)N);
+    if (in_len > ir->L && in_len + ir->M - 1 > N)
+        return fail(WP_ERR_UNSUPPORTED, "input of %lld samples wraps circularly in the reference's %lld-point FFT; not implemented", (long long)in_len, (long long)N);
+    return WP_OK;
+}
+
+extern "C" int wp_conv_run_dev(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len, float *out_dev,
+                               int64_t out_stride, const float *prev_dev, int64_t prev_stride, int64_t prev_len,
+                               void *stream)
+{
+    if (int rc = need_device()) return rc;
+    if (!c || !out_dev || (!in_dev && in_len > 0)) return fail(WP_ERR_INVALID, "wp_conv_run_dev: null argument");
+    const wp_ir *ir = c->ir;
+    if (int rc = check_in_len(ir, in_len)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = ir->B, T = c->T;
+    int Tin = (int)((in_len + B - 1) / B) + 1;
+    if (Tin > T) Tin = T;
+    if (in_len == 0) Tin = 0;
+    if (Tin > 0) HIPCHK(launch_fft_fwd(B, false, in_dev, in_stride, in_len, c->Z, T, Tin, c->njobs, ir->tables, s));
+    HIPCHK(launch_mac(ir->PG, c->Z, c->W, ir->Hp, ir->tables + table_wsplit_offset(B), c->job_irch, B, T, Tin, ir->Pp,
+                      c->njobs, c->tchunk, s));
+    if (prev_dev && prev_len > ir->L + ir->M) prev_len = ir->L + ir->M;
+    HIPCHK(launch_fft_inv(B, c->W, T, c->njobs, out_dev, out_stride, ir->L + ir->M, prev_len > 0 ? prev_dev : nullptr,
+                          prev_stride, prev_len, ir->tables, s));
+    return WP_OK;
+}
+
+extern "C" int wp_convolve(wp_ir *ir, int ch, const float *in, int64_t in_len, float *out)
+{
+    if (int rc = need_device()) return rc;
+    if (!ir || !out || (!in && in_len > 0)) return fail(WP_ERR_INVALID, "wp_convolve: null argument");
+    if (ch < 0 || ch >= ir->nch) return fail(WP_ERR_INVALID, "wp_convolve: IR channel %d of %d", ch, ir->nch);
+    if (int rc = check_in_len(ir, in_len)) return rc;
+    const int64_t N = wp_next_pot((int32_t)(ir->L + ir->M));
+    if (!ir->single) {
+        const int32_t zero = 0;
+        ir->single = wp_conv_create(ir, 1, &zero);
+        if (!ir->single) return WP_ERR_HIP;
+        HIPCHK(hipMalloc((void **)&ir->stage_in, sizeof(float) * (size_t)(N + 2)));
+        HIPCHK(hipMalloc((void **)&ir->stage_out, sizeof(float) * (size_t)(ir->L + ir->M + 2)));
+    }
+    HIPCHK(hipMemcpy(ir->single->job_irch, &ch, sizeof(int32_t), hipMemcpyHostToDevice));
+    if (in_len > 0) HIPCHK(hipMemcpy(ir->stage_in, in, sizeof(float) * (size_t)in_len, hipMemcpyHostToDevice));
+    if (int rc = wp_conv_run_dev(ir->single, ir->stage_in, 0, in_len, ir->stage_out, 0, nullptr, 0, 0, nullptr)) return rc;
+    HIPCHK(hipMemcpy(out, ir->stage_out, sizeof(float) * (size_t)(ir->L + ir->M), hipMemcpyDeviceToHost));
+    return WP_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" wp_reverb *wp_reverb_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t offset)
+{
+    if (need_device()) return nullptr;
+    wp_conv *c = wp_conv_create(ir, njobs, job_ch);
+    if (!c) return nullptr;
+    wp_reverb *r = new wp_reverb();
+    r->conv = c;
+    r->njobs = njobs;
+    r->offset = offset;
+    r->stride = (ir->L + ir->M + 3) & ~(int64_t)3;
+    r->buf[0] = r->buf[1] = nullptr;
+    r->cur = 0;
+    r->prev_off = r->prev_len = 0;
+    r->stage_in = nullptr;
+    r->stage_in_len = 0;
+    const size_t bytes = sizeof(float) * (size_t)njobs * r->stride;
+    hipError_t e = hipMalloc((void **)&r->buf[0], bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->buf[1], bytes);
+    if (e != hipSuccess) {
+        fail(WP_ERR_HIP, "wp_reverb_create: hipMalloc failed: %s", hipGetErrorString(e));
+        wp_reverb_destroy(r);
+        return nullptr;
+    }
+    return r;
+}
+
+extern "C" void wp_reverb_destroy(wp_reverb *r)
+{
+    if (!r) return;
+    if (r->buf[0]) (void)hipFree(r->buf[0]);
+    if (r->buf[1]) (void)hipFree(r->buf[1]);
+    if (r->stage_in) (void)hipFree(r->stage_in);
+    if (r->conv) wp_conv_destroy(r->conv);
+    delete r;
+}
+
+extern "C" int wp_reverb_block_dev(wp_reverb *r, const float *in_dev, int64_t in_stride, int64_t in_len,
+                                   float **curr_dev, int64_t *curr_stride, wp_reverb_view *v, void *stream)
+{
+    if (int rc = need_device()) return rc;
+    if (!r || !v) return fail(WP_ERR_INVALID, "wp_reverb_block_dev: null argument");
+    const wp_ir *ir = r->conv->ir;
+    const int nxt = r->cur ^ 1;
+    const float *prev = r->prev_len > 0 ? r->buf[r->cur] + r->prev_off : nullptr;
+    if (int rc = wp_conv_run_dev(r->conv, in_dev, in_stride, in_len, r->buf[nxt], r->stride, prev, r->stride,
+                                 r->prev_len, stream))
+        return rc;
+    wp_reverb_view_for(ir->L, ir->M, r->offset, in_len, v);
+    r->cur = nxt;
+    r->prev_off = v->prev_off;
+    r->prev_len = v->prev_len;
+    if (curr_dev) *curr_dev = r->buf[nxt];
+    if (curr_stride) *curr_stride = r->stride;
+    return WP_OK;
+}
+
+extern "C" int wp_reverb_block(wp_reverb *r, const float *const *in, int64_t in_len, float *const *out,
+                               wp_reverb_view *v)
+{
+    if (int rc = need_device()) return rc;
+    if (!r || !in || !out || !v) return fail(WP_ERR_INVALID, "wp_reverb_block: null argument");
+    const wp_ir *ir = r->conv->ir;
+    if (int rc = check_in_len(ir, in_len)) return rc;
+    const int64_t istride = (in_len + 3) & ~(int64_t)3;
+    if (r->stage_in_len < istride) {
+        if (r->stage_in) (void)hipFree(r->stage_in);
+        r->stage_in = nullptr;
+        r->stage_in_len = 0;
+        HIPCHK(hipMalloc((void **)&r->stage_in, sizeof(float) * (size_t)r->njobs * (istride > 0 ? istride : 4)));
+        r->stage_in_len = istride;
+    }
+    for (int j = 0; j < r->njobs; j++)
+        if (in_len > 0)
+            HIPCHK(hipMemcpy(r->stage_in + (size_t)j * istride, in[j], sizeof(float) * (size_t)in_len, hipMemcpyHostToDevice));
+    float *curr = nullptr;
+    int64_t cs = 0;
+    if (int rc = wp_reverb_block_dev(r, r->stage_in, istride, in_len, &curr, &cs, v, nullptr)) return rc;
+    for (int j = 0; j < r->njobs; j++)
+        HIPCHK(hipMemcpy(out[j], curr + (size_t)j * cs, sizeof(float) * (size_t)(ir->L + ir->M), hipMemcpyDeviceToHost));
+    return WP_OK;
+}
+
+extern "C" int wp_reverb_set_tail(wp_reverb *r, const float *const *prev, int64_t prev_len)
+{
+    if (int rc = need_device()) return rc;
+    if (!r || (prev_len > 0 && !prev)) return fail(WP_ERR_INVALID, "wp_reverb_set_tail: null argument");
+    const wp_ir *ir = r->conv->ir;
+    if (prev_len < 0) prev_len = 0;
+    if (prev_len > ir->L + ir->M) prev_len = ir->L + ir->M;  // adds past curr.length are no-ops on a typed array
+    for (int j = 0; j < r->njobs && prev_len > 0; j++)
+        HIPCHK(hipMemcpy(r->buf[r->cur] + (size_t)j * r->stride, prev[j], sizeof(float) * (size_t)prev_len, hipMemcpyHostToDevice));
+    r->prev_off = 0;
+    r->prev_len = prev_len;
+    return WP_OK;
+}
+
+extern "C" int64_t wp_reverb_tail_len(const wp_reverb *r) { return r ? r->prev_len : WP_ERR_INVALID; }
+
+extern "C" int wp_reverb_get_tail(wp_reverb *r, float *const *prev_out)
+{
+    if (int rc = need_device()) return rc;
+    if (!r || !prev_out) return fail(WP_ERR_INVALID, "wp_reverb_get_tail: null argument");
+    for (int j = 0; j < r->njobs && r->prev_len > 0; j++)
+        HIPCHK(hipMemcpy(prev_out[j], r->buf[r->cur] + (size_t)j * r->stride + r->prev_off, sizeof(float) * (size_t)r->prev_len, hipMemcpyDeviceToHost));
+    return WP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// mix
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+static std::map<int, Scratch> g_mix_scratch;  // per device: wp_src copy + mix_desc array
+
+static int mix_scratch(int dev, size_t bytes, hipStream_t s, void **out)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    Scratch &sc = g_mix_scratch[dev];
+    if (sc.cap < bytes) {
+        if (sc.p) {
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipFree(sc.p));
+            sc.p = nullptr;
+            sc.cap = 0;
+        }
+        size_t cap = bytes < (1 << 20) ? (1 << 20) : bytes;
+        HIPCHK(hipMalloc(&sc.p, cap));
+        sc.cap = cap;
+    }
+    *out = sc.p;
+    return WP_OK;
+}
+
+extern "C" int wp_mix_dev(float *const *tgt_dev, int tch, int64_t tl, const wp_src *srcs, int64_t nsrc,
+                          int srcs_on_device, void *stream)
+{
+    if (int rc = need_device()) return rc;
+    if (!tgt_dev || tl < 0 || nsrc < 0 || (nsrc > 0 && !srcs)) return fail(WP_ERR_INVALID, "wp_mix_dev: bad argument");
+    if (tch < 1 || !tgt_dev[0] || (tch >= 2 && !tgt_dev[1])) return fail(WP_ERR_INVALID, "wp_mix_dev: null target channel");
+    if (nsrc == 0 || tl == 0) return WP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    const size_t src_bytes = (sizeof(wp_src) * (size_t)nsrc + 255) & ~(size_t)255;
+    const size_t bytes = src_bytes + mix_desc_bytes() * (size_t)nsrc;
+    void *scr = nullptr;
+    if (int rc = mix_scratch(dev, bytes, s, &scr)) return rc;
+    const wp_src *sd = srcs;
+    if (!srcs_on_device) {
+        HIPCHK(hipMemcpyAsync(scr, srcs, sizeof(wp_src) * (size_t)nsrc, hipMemcpyHostToDevice, s));
+        sd = reinterpret_cast<const wp_src *>(scr);
+    }
+    HIPCHK(launch_mix(tgt_dev[0], tch >= 2 ? tgt_dev[1] : nullptr, tch, tl, sd, (char *)scr + src_bytes, nsrc, s));
+    return WP_OK;
+}
+
+extern "C" int wp_mix(float *const *tgt, int tch, int64_t tl, const wp_src *srcs, int64_t nsrc)
+{
+    if (int rc = need_device()) return rc;
+    if (!tgt || tl < 0 || nsrc < 0 || (nsrc > 0 && !srcs)) return fail(WP_ERR_INVALID, "wp_mix: bad argument");
+    if (tch < 1 || !tgt[0] || (tch >= 2 && !tgt[1])) return fail(WP_ERR_INVALID, "wp_mix: null target channel");
+    if (nsrc == 0 || tl == 0 || tch > 2) return WP_OK;
+    // stage every distinct host array once
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    std::map<std::pair<const void *, size_t>, size_t> where;  // (host ptr, bytes) -> offset
+    size_t total = 0;
+    auto place = [&](const void *p, size_t bytes) {
+        auto key = std::make_pair(p, bytes);
+        auto it = where.find(key);
+        if (it == where.end()) {
+            where[key] = total;
+            total += al(bytes);
+        }
+    };
+    for (int c = 0; c < tch; c++) place(tgt[c], sizeof(float) * (size_t)tl);
+    for (int64_t i = 0; i < nsrc; i++) {
+        const wp_src &S = srcs[i];
+        if (S.nch != 1 && S.nch != 2) continue;
+        if (S.rl < 0) return fail(WP_ERR_INVALID, "wp_mix: source %lld has negative length", (long long)i);
+        for (int c = 0; c < S.nch; c++) {
+            if (!S.ch[c] && S.rl > 0) return fail(WP_ERR_INVALID, "wp_mix: source %lld channel %d is null", (long long)i, c);
+            place(S.ch[c], sizeof(float) * (size_t)S.rl);
+        }
+        if (S.vol_vec) place(S.vol_vec, sizeof(double) * (size_t)tl);
+    }
+    char *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, total > 0 ? total : 256));
+    int rc = WP_OK;
+    auto cleanup = [&]() { (void)hipFree(d); };
+    for (auto &kv : where) {
+        if (kv.first.second == 0) continue;
+        hipError_t e = hipMemcpy(d + kv.second, kv.first.first, kv.first.second, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            cleanup();
+            return fail(WP_ERR_HIP, "hipMemcpy(H2D) failed: %s", hipGetErrorString(e));
+        }
+    }
+    std::vector<wp_src> ds(srcs, srcs + nsrc);
+    for (int64_t i = 0; i < nsrc; i++) {
+        wp_src &S = ds[i];
+        if (S.nch != 1 && S.nch != 2) continue;
+        for (int c = 0; c < S.nch; c++)
+            S.ch[c] = reinterpret_cast<const float *>(d + where[std::make_pair((const void *)srcs[i].ch[c], sizeof(float) * (size_t)S.rl)]);
+        if (S.vol_vec)
+            S.vol_vec = reinterpret_cast<const double *>(d + where[std::make_pair((const void *)srcs[i].vol_vec, sizeof(double) * (size_t)tl)]);
+    }
+    float *td[2] = {nullptr, nullptr};
+    for (int c = 0; c < tch; c++)
+        td[c] = reinterpret_cast<float *>(d + where[std::make_pair((const void *)tgt[c], sizeof(float) * (size_t)tl)]);
+    rc = wp_mix_dev(td, tch, tl, ds.data(), nsrc, 0, nullptr);
+    if (rc == WP_OK) {
+        for (int c = 0; c < tch && rc == WP_OK; c++) {
+            hipError_t e = hipMemcpy(tgt[c], td[c], sizeof(float) * (size_t)tl, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) rc = fail(WP_ERR_HIP, "hipMemcpy(D2H) failed: %s", hipGetErrorString(e));
+        }
+    }
+    cleanup();
+    return rc;
+}

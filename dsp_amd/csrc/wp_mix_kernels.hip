@@ -1,0 +1,238 @@
+// wp_mix_kernels.hip — bandwidth-bound multi-source mix-reduce, the gfx950
+// counterpart of src/mix-buffers.js:1-73.
+//
+// Built with -ffp-contract=off: the reference evaluates
+//     target[x] = f32( f64(target[x]) + f64(src[idx]) * vol )
+// with a separately rounded binary64 multiply and add per source, in source
+// order; doing exactly that here makes the single-GPU result bit-identical.
+//
+// Layout: one thread owns 4 consecutive target frames (both target channels)
+// and walks the sources in order, so every source channel is read exactly once
+// with 16-byte accesses and the target is read and written once: the kernel's
+// traffic is the algorithmic minimum, 4*(source channels) + 8*(target channels)
+// bytes per frame.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "wp_internal.h"
+
+namespace wp {
+
+// internal per-source record, produced on the device by k_mix_prep
+struct mix_desc {
+    const float *ch0;
+    const float *ch1;
+    const double *vol_vec;
+    double vol;
+    int64_t rl;
+    int64_t asl;   // |sl|
+    int64_t o;
+    int64_t base;  // contiguous mode: index of frame 0 in the source
+    int32_t nch;
+    int32_t mode;  // 0 skip, 1 every sample NaN, 2 contiguous, 3 general modular indexing
+};
+
+enum { MIX_SKIP = 0, MIX_NAN = 1, MIX_CONTIG = 2, MIX_GENERAL = 3 };
+
+// src/mix-buffers.js:5-14 decoded once per source (one thread each).
+__global__ void k_mix_prep(const wp_src *__restrict__ srcs, mix_desc *__restrict__ out, int64_t nsrc, int64_t tl,
+                           int tch)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsrc) return;
+    const wp_src S = srcs[s];
+    mix_desc d;
+    d.ch0 = S.ch[0];
+    d.ch1 = S.nch == 2 ? S.ch[1] : S.ch[0];
+    d.vol_vec = S.vol_vec;
+    d.vol = S.vol;
+    d.rl = S.rl;
+    d.asl = S.sl < 0 ? -S.sl : S.sl;
+    d.o = S.o;
+    d.base = 0;
+    d.nch = S.nch;
+    if ((S.nch != 1 && S.nch != 2) || (tch != 1 && tch != 2)) {
+        d.mode = MIX_SKIP;  // the reference silently ignores other layouts (:18-44, :47-69)
+    } else if (d.asl == 0 || S.rl <= 0) {
+        d.mode = MIX_NAN;   // x % 0 is NaN -> undefined -> NaN
+    } else {
+        d.mode = MIX_GENERAL;
+        if (S.o >= 0) {
+            const int64_t om = S.o % d.asl;
+            if (om + tl <= d.asl && om + tl <= S.rl) {
+                d.mode = MIX_CONTIG;
+                d.base = om;
+            }
+        }
+    }
+    out[s] = d;
+}
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
+
+struct quad {
+    float v[4];
+};
+
+// fetch the 4 source samples this thread needs from one channel
+__device__ __forceinline__ void fetch_contig(const float *__restrict__ p, int nf, quad &q)
+{
+    if (nf == 4) {
+        const f4u t = *reinterpret_cast<const f4u *>(p);
+        q.v[0] = t.x; q.v[1] = t.y; q.v[2] = t.z; q.v[3] = t.w;
+    } else {
+#pragma unroll
+        for (int f = 0; f < 4; f++) q.v[f] = f < nf ? p[f] : 0.0f;
+    }
+}
+
+// (x+o) % sl % rl with JavaScript remainder semantics (src/mix-buffers.js:22):
+// negative index -> undefined -> NaN, except -0 which names element 0.
+__device__ __forceinline__ void fetch_general(const mix_desc &d, int64_t x0, int nf, quad &q0, quad &q1)
+{
+    const float nanv = __builtin_nanf("");
+    int64_t v = 0, i = 0;
+    bool have = false;
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        if (f >= nf) { q0.v[f] = q1.v[f] = 0.0f; continue; }
+        const int64_t a = x0 + f + d.o;
+        if (a < 0) {
+            if (a % d.asl == 0) { q0.v[f] = d.ch0[0]; q1.v[f] = d.ch1[0]; }
+            else { q0.v[f] = q1.v[f] = nanv; }
+            continue;
+        }
+        if (!have) {
+            v = a % d.asl;
+            i = v % d.rl;
+            have = true;
+        } else {
+            v++; i++;
+            if (i == d.rl) i = 0;
+            if (v == d.asl) { v = 0; i = 0; }
+        }
+        q0.v[f] = d.ch0[i];
+        q1.v[f] = d.ch1[i];
+    }
+}
+
+template <int TCH>
+__global__ __launch_bounds__(256) void k_mix(float *__restrict__ t0, float *__restrict__ t1, int64_t tl,
+                                             const mix_desc *__restrict__ descs, int64_t nsrc)
+{
+    const int64_t x0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x0 >= tl) return;
+    const int nf = (tl - x0 >= 4) ? 4 : (int)(tl - x0);
+    quad a0, a1;
+    fetch_contig(t0 + x0, nf, a0);
+    if (TCH == 2) fetch_contig(t1 + x0, nf, a1);
+
+    constexpr int U = 4;  // sources fetched ahead of the (sequential) accumulation
+    for (int64_t s0 = 0; s0 < nsrc; s0 += U) {
+        quad q0[U], q1[U];
+        double vv[U][4];
+        int mode[U], nch[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            mode[u] = MIX_SKIP;
+            nch[u] = 0;
+            if (s0 + u < nsrc) {
+                const mix_desc &d = descs[s0 + u];
+                mode[u] = d.mode;
+                nch[u] = d.nch;
+                if (d.mode == MIX_CONTIG) {
+                    fetch_contig(d.ch0 + d.base + x0, nf, q0[u]);
+                    if (d.nch == 2) fetch_contig(d.ch1 + d.base + x0, nf, q1[u]);
+                } else if (d.mode == MIX_GENERAL) {
+                    fetch_general(d, x0, nf, q0[u], q1[u]);
+                } else if (d.mode == MIX_NAN) {
+#pragma unroll
+                    for (int f = 0; f < 4; f++) q0[u].v[f] = q1[u].v[f] = __builtin_nanf("");
+                }
+                if (d.mode != MIX_SKIP) {
+                    if (d.vol_vec) {
+#pragma unroll
+                        for (int f = 0; f < 4; f++) vv[u][f] = f < nf ? d.vol_vec[x0 + f] : 0.0;
+                    } else {
+#pragma unroll
+                        for (int f = 0; f < 4; f++) vv[u][f] = d.vol;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (mode[u] == MIX_SKIP) continue;
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+                const double vol = vv[u][f];
+                if (TCH == 2) {
+                    if (nch[u] == 2) {  // stereo -> stereo (:22-23, :50-51)
+                        a0.v[f] = (float)((double)a0.v[f] + (double)q0[u].v[f] * vol);
+                        a1.v[f] = (float)((double)a1.v[f] + (double)q1[u].v[f] * vol);
+                    } else {            // mono -> stereo (:28-29, :55-56)
+                        const double h = ((double)q0[u].v[f] / 2.0) * vol;
+                        a0.v[f] = (float)((double)a0.v[f] + h);
+                        a1.v[f] = (float)((double)a1.v[f] + h);
+                    }
+                } else {
+                    if (nch[u] == 2)    // stereo -> mono (:36, :62)
+                        a0.v[f] = (float)((double)a0.v[f] + (((double)q0[u].v[f] + (double)q1[u].v[f]) / 2.0) * vol);
+                    else                // mono -> mono (:41, :66)
+                        a0.v[f] = (float)((double)a0.v[f] + (double)q0[u].v[f] * vol);
+                }
+            }
+        }
+    }
+    if (nf == 4) {
+        f4u o;
+        o.x = a0.v[0]; o.y = a0.v[1]; o.z = a0.v[2]; o.w = a0.v[3];
+        *reinterpret_cast<f4u *>(t0 + x0) = o;
+        if (TCH == 2) {
+            o.x = a1.v[0]; o.y = a1.v[1]; o.z = a1.v[2]; o.w = a1.v[3];
+            *reinterpret_cast<f4u *>(t1 + x0) = o;
+        }
+    } else {
+        for (int f = 0; f < nf; f++) {
+            t0[x0 + f] = a0.v[f];
+            if (TCH == 2) t1[x0 + f] = a1.v[f];
+        }
+    }
+}
+
+size_t mix_desc_bytes() { return sizeof(mix_desc); }
+
+hipError_t launch_mix(float *t0, float *t1, int tch, int64_t tl, const wp_src *srcs_dev, void *desc_scratch,
+                      int64_t nsrc, hipStream_t s)
+{
+    if (nsrc <= 0 || tl <= 0) return hipSuccess;
+    mix_desc *descs = reinterpret_cast<mix_desc *>(desc_scratch);
+    hipLaunchKernelGGL(k_mix_prep, dim3((unsigned)((nsrc + 255) / 256)), dim3(256), 0, s, srcs_dev, descs, nsrc, tl, tch);
+    if (tch != 1 && tch != 2) return hipGetLastError();  // nothing to do (reference: silently nothing)
+    const int64_t nthreads = (tl + 3) / 4;
+    const dim3 grid((unsigned)((nthreads + 255) / 256)), block(256);
+    if (tch == 2) hipLaunchKernelGGL((k_mix<2>), grid, block, 0, s, t0, t1, tl, descs, nsrc);
+    else hipLaunchKernelGGL((k_mix<1>), grid, block, 0, s, t0, t1, tl, descs, nsrc);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// synthetic noise: murmur3 finaliser over the sample index, 24-bit mantissa
+__global__ void k_synth_noise(float *__restrict__ out, int64_t n, uint32_t k, int64_t start)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t h = (uint32_t)(start + i) ^ k;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    out[i] = (float)((int32_t)(h >> 8) - 8388608) * (1.0f / 8388608.0f);
+}
+
+hipError_t launch_synth_noise(float *out, int64_t n, uint32_t seed, int64_t start, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_synth_noise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n, seed * 0x9E3779B9u, start);
+    return hipGetLastError();
+}
+
+}  // namespace wp

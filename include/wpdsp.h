@@ -1,0 +1,164 @@
+/*
+ * wpdsp.h — C ABI of libwpdsp.so: the MI355X (gfx950) implementation of
+ * wavepot/dsp's convolution-reverb and mix-buffers hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or framework
+ * types.  The Node N-API addon (dsp_amd/napi/wpdsp_napi.cc), the JavaScript
+ * shims (dsp_amd/js/) and the Python binding (dsp_amd/capi.py) are thin callers
+ * of exactly these entry points.  Each declaration names the reference code it
+ * stands in for (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - Functions returning int: 0 on success, negative WP_ERR_* on failure;
+ *     wp_last_error() gives the message for the calling thread.
+ *   - "_dev" entry points take device pointers and a hipStream_t (as void*;
+ *     NULL = the default stream) and are asynchronous on that stream.  The others
+ *     take host pointers, copy in and out, and return when the result is in
+ *     host memory.
+ *   - Handles belong to the HIP device that was current when they were created.
+ *     One handle must not be used from two threads at once; different handles
+ *     may be.
+ *   - Without a usable GPU every compute entry point fails with
+ *     WP_ERR_NO_DEVICE.  There is no CPU fallback.
+ */
+#ifndef WPDSP_H
+#define WPDSP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WP_OK 0
+#define WP_ERR_INVALID (-1)     /* bad argument */
+#define WP_ERR_RANGE (-2)       /* input longer than the FFT size: RangeError in the reference (lib/convolve.js:590) */
+#define WP_ERR_FFT_SIZE (-3)    /* "FFT size must be a power of two and bigger than 1" (lib/convolve.js:8-9) */
+#define WP_ERR_NO_DEVICE (-4)   /* no HIP device / runtime failure at init */
+#define WP_ERR_HIP (-5)         /* a HIP call failed; see wp_last_error() */
+#define WP_ERR_UNSUPPORTED (-6) /* valid in the reference, not implemented here; message says what */
+
+typedef struct wp_ir wp_ir;         /* device-resident partitioned spectra of an impulse response */
+typedef struct wp_conv wp_conv;     /* a batch of channel-jobs convolving with one wp_ir */
+typedef struct wp_reverb wp_reverb; /* wp_conv + carried tail per job (block reverb) */
+
+/* Number of visible HIP devices, or WP_ERR_NO_DEVICE.  Idempotent, thread-safe. */
+int wp_init(void);
+/* Message for the last failure on the calling thread ("" if none). */
+const char *wp_last_error(void);
+
+/* lib/convolve.js:521-530 nextPowerOfTwo (int32 bit smear; 0 -> 1). */
+int32_t wp_next_pot(int32_t n);
+/* lib/convolve.js:554-555, 565-566: FFT size the reference would use for block
+ * length L and kernel length M; the interleaved spectrum it caches has 2x this
+ * many floats. */
+int32_t wp_fft_length(int64_t L, int64_t M);
+
+/* ---- impulse response --------------------------------------------------- */
+/* lib/convolve.js:553-562 fftProcessKernel(length, kernel), for nch kernels of
+ * M samples each (host memory): builds the partition spectra on the device.
+ * L is the block length the caller convolves with (c.buffer[0].length in
+ * lib/impulse-convolve.js:12, impulse-convolve-stereo.js:14-15); it fixes the
+ * result length L+M and the partition size.  NULL on failure. */
+wp_ir *wp_ir_create(const float *const *ir, int nch, int64_t M, int64_t L);
+/* Same with the IR already on the device: channel c starts at ir_dev + c*ch_stride. */
+wp_ir *wp_ir_create_dev(const float *ir_dev, int nch, int64_t ch_stride, int64_t M, int64_t L, void *stream);
+void wp_ir_destroy(wp_ir *ir);
+/* which: 0 M, 1 L, 2 channels, 3 partition size B, 4 partitions P, 5 result length L+M,
+ * 6 reference FFT length, 7 device bytes held. */
+int64_t wp_ir_info(const wp_ir *ir, int which);
+
+/* ---- convolution: lib/convolve.js:564-586 fftConvolution(...) -> go(input) - */
+/* One go(input): ch picks the IR channel; in_len <= reference FFT length, else
+ * WP_ERR_RANGE; out receives exactly L+M floats. */
+int wp_convolve(wp_ir *ir, int ch, const float *in, int64_t in_len, float *out);
+
+/* Batched: njobs independent go() calls sharing one launch sequence.  job_ch[j]
+ * (host array) is the IR channel job j uses. */
+wp_conv *wp_conv_create(wp_ir *ir, int njobs, const int32_t *job_ch);
+void wp_conv_destroy(wp_conv *c);
+/* Job j reads in_dev + j*in_stride (in_len samples) and writes L+M samples at
+ * out_dev + j*out_stride.  If prev_dev is non-NULL, prev_dev[j*prev_stride + i]
+ * is added to output sample i for i < prev_len (lib/impulse-reverb.js:14-16). */
+int wp_conv_run_dev(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len, float *out_dev,
+                    int64_t out_stride, const float *prev_dev, int64_t prev_stride, int64_t prev_len,
+                    void *stream);
+/* Device bytes of workspace a wp_conv holds. */
+int64_t wp_conv_workspace_bytes(const wp_conv *c);
+
+/* ---- block reverb: lib/impulse-reverb.js:10-21, impulse-reverb-stereo.js:11-30 */
+/* Index bookkeeping of one reverb block, in samples relative to the start of
+ * the (L+M)-sample result buffer `curr`:
+ *   ret  = curr.subarray(offset, offset+len)      (impulse-reverb.js:20)
+ *   prev = curr.subarray(-tail), tail = (L+M-offset)-len   (:17-18), with
+ *          TypedArray.subarray's clamping (tail == 0 keeps everything, tail < 0
+ *          drops |tail| samples from the front). */
+typedef struct wp_reverb_view {
+    int64_t curr_len; /* L+M */
+    int64_t ret_off, ret_len;
+    int64_t prev_off, prev_len;
+} wp_reverb_view;
+/* Pure integer helper (no GPU): the view for block length len. */
+int wp_reverb_view_for(int64_t L, int64_t M, int64_t offset, int64_t len, wp_reverb_view *v);
+
+/* njobs channel-jobs (mono reverb: 1, stereo: 2 with job_ch = {0,1}; a batch of
+ * tracks: 2*tracks), each with its own carried tail. */
+wp_reverb *wp_reverb_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t offset);
+void wp_reverb_destroy(wp_reverb *r);
+/* One block for every job, host buffers: in[j] has in_len samples, out[j]
+ * receives the whole curr buffer (L+M floats, tail already added); *v tells
+ * which parts the reference returns and carries. */
+int wp_reverb_block(wp_reverb *r, const float *const *in, int64_t in_len, float *const *out, wp_reverb_view *v);
+/* Same on the device: job j reads in_dev + j*in_stride; *curr_dev is set to the
+ * library-owned result (job j at *curr_dev + j*(*curr_stride)), valid until the
+ * next-but-one block. */
+int wp_reverb_block_dev(wp_reverb *r, const float *in_dev, int64_t in_stride, int64_t in_len, float **curr_dev,
+                        int64_t *curr_stride, wp_reverb_view *v, void *stream);
+/* Carried tail in/out (the value lib/impulse-reverb.js:6,19 keeps under
+ * 'prev:'+id+url+n): prev[j] has prev_len samples. */
+int wp_reverb_set_tail(wp_reverb *r, const float *const *prev, int64_t prev_len);
+int64_t wp_reverb_tail_len(const wp_reverb *r);
+int wp_reverb_get_tail(wp_reverb *r, float *const *prev_out);
+
+/* ---- mix: src/mix-buffers.js:1-73 ---------------------------------------- */
+/* One decoded source (src/mix-buffers.js:5-14).  target[c][x] +=
+ * f(src[(x+o) % sl % rl]) * vol, evaluated per source in order with binary64
+ * multiply and add and a binary32 store, exactly as the reference does. */
+typedef struct wp_src {
+    const float *ch[2];    /* channel pointers; ch[1] ignored when nch == 1 */
+    int32_t nch;           /* 1 or 2; anything else is skipped like the reference does */
+    int32_t flags;         /* reserved, 0 */
+    int64_t rl;            /* real length: source[0].length (:11,:13) */
+    int64_t sl;            /* (rl*length)|0 for the tuple form (:7), rl for the plain form */
+    double vol;            /* source[2] ?? 1 (:8) */
+    const double *vol_vec; /* if non-NULL, gain per target frame: _vol(x) (:21), tl entries */
+    int64_t o;             /* source[3] ?? 0 (:9) */
+} wp_src;
+/* src/mix-buffers.js:7: sl = (rl*length)|0 with JavaScript ToInt32 semantics. */
+int32_t wp_mix_sl(int64_t rl, double length);
+/* Host buffers: tgt[0..tch) of tl floats are updated in place. */
+int wp_mix(float *const *tgt, int tch, int64_t tl, const wp_src *srcs, int64_t nsrc);
+/* Device buffers: every pointer inside tgt_dev/srcs is a device pointer; the
+ * srcs array itself is in host memory unless srcs_on_device != 0. */
+int wp_mix_dev(float *const *tgt_dev, int tch, int64_t tl, const wp_src *srcs, int64_t nsrc, int srcs_on_device,
+               void *stream);
+
+/* ---- integer helpers ------------------------------------------------------ */
+/* lib/ring-buffer.js:10-22,33-50: element a proxy access at `key` touches. */
+int64_t wp_ring_pos(int64_t needle, int64_t key, int64_t length);
+/* lib/ring-buffer.js:35-39: needle after a write at key 0. */
+int64_t wp_ring_advance(int64_t needle, int64_t length);
+/* src/loop-node.js:145-147 beatRate; :48-50 bufferSize = 4*beatRate. */
+int64_t wp_beat_rate(double sample_rate, double bpm);
+
+/* ---- synthetic inputs for tests and benchmarks (no reference counterpart) --- */
+/* out[i] = ((fmix32((start+i) ^ seed*0x9E3779B9) >> 8) - 2^23) / 2^23, on the device. */
+int wp_synth_noise_dev(float *out_dev, int64_t n, uint32_t seed, int64_t start, void *stream);
+/* Decaying-noise IR, L1-normalised, computed on the host with IEEE basic
+ * operations only (bit-reproducible everywhere). */
+int wp_synth_ir(float *out_host, int64_t M, uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WPDSP_H */

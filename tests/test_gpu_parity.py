@@ -1,0 +1,228 @@
+"""GPU parity: the HIP path, called through the C ABI (dsp_amd.* are ctypes
+callers of libwpdsp.so), against (a) the golden vectors recorded from the
+reference JavaScript and (b) the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for integer/index work and for the mix (f64 multiply/add, f32
+store per source, source order); max abs error <= 1e-5 of full scale for
+convolution samples (full scale = 1.0; the tiny vectors whose values exceed 1
+are scaled by their peak).
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal, from_bits, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _close(actual, expected, what, tol=TOL):
+    a = np.asarray(actual, dtype=np.float64)
+    e = np.asarray(expected, dtype=np.float64)
+    assert a.shape == e.shape, "%s: length %s != %s" % (what, a.shape, e.shape)
+    fs = max(1.0, float(np.abs(e).max()) if e.size else 1.0)
+    err = float(np.abs(a - e).max()) if e.size else 0.0
+    assert err <= tol * fs, "%s: max abs err %.3e > %.1e of full scale %.3g" % (what, err, tol, fs)
+    return err
+
+
+@pytest.fixture(scope="module")
+def wp():
+    from dsp_amd import capi, convolve, impulse, mix
+    assert capi.init() >= 1
+
+    class NS:
+        pass
+    ns = NS()
+    ns.capi, ns.convolve, ns.impulse, ns.mix = capi, convolve, impulse, mix
+    return ns
+
+
+def test_g1_tiny_go_vectors(wp):
+    g = load_golden("g1_convolve_tiny.json")
+    for c in g["cases"]:
+        x, h = from_bits(c["x"]), from_bits(c["h"])
+        k = wp.convolve.fft_process_kernel(c["L"], h)
+        assert len(k) == c["kernel_len"]
+        y = wp.convolve.fft_convolution(c["L"], k, len(h))(x)
+        assert len(y) == c["out_len"] and y.dtype == np.float32
+        _close(y, from_bits(c["out"]), "go L=%d M=%d" % (c["L"], c["M"]))
+        d = wp.convolve.direct_convolution(x, h)
+        _close(d, from_bits(c["direct"]), "direct L=%d" % c["L"])
+
+
+def test_error_behaviour(wp):
+    k = wp.convolve.fft_process_kernel(4, np.ones(4, np.float32))
+    go = wp.convolve.fft_convolution(4, k, 4)
+    with pytest.raises(IndexError):        # RangeError in the reference (convolve.js:590)
+        go(np.zeros(9, np.float32))
+    with pytest.raises(ValueError):        # 'FFT size must be a power of two and bigger than 1'
+        wp.convolve.fft_process_kernel(0, np.zeros(1, np.float32))
+    assert len(go(np.zeros(0, np.float32))) == 8   # empty input: L+M zeros
+    assert not go(np.zeros(0, np.float32)).any()
+    y = go(np.array([1, 0], np.float32))           # ragged: shorter than L
+    _close(y, [1, 1, 1, 1, 0, 0, 0, 0], "short input")
+
+
+def test_g3_reverb_block_sequences(wp, oracle):
+    g = load_golden("g3_reverb_blocks.json")
+    for run in g["runs"]:
+        p = dict(run["params"])
+        url = p.pop("url")
+        store, log = {}, []
+        make = wp.impulse.impulse_reverb_stereo if run["kind"] == "stereo" else wp.impulse.impulse_reverb
+        irs = {url: [from_bits(b).copy() for b in run["ir"]]}
+        ctx = lambda blk: oracle.StubContext([from_bits(b).copy() for b in blk["input"]], blk["n"], irs, store, log)
+        c0 = ctx(run["blocks"][0])
+        fn = make(c0, url, **p)
+        for i, blk in enumerate(run["blocks"]):
+            c = c0 if i == 0 else ctx(blk)
+            ret = fn(c)
+            ret = [ret] if run["kind"] == "mono" else ret
+            what = "%s %s block %d" % (run["kind"], run["params"], i)
+            for ch, exp in enumerate(blk["ret"]):
+                # index work is bit-exact: view length, byte offset, backing buffer size
+                assert len(ret[ch]) == exp["length"], what
+                base = ret[ch].base if ret[ch].base is not None else ret[ch]
+                off = ret[ch].__array_interface__["data"][0] - base.__array_interface__["data"][0]
+                assert off == exp["byte_offset"], what
+                assert base.nbytes == exp["buffer_bytes"], what
+                _close(ret[ch], from_bits(exp["data"]), what)
+                _close(base, from_bits(exp["full"]), what + " full buffer")
+            prev = store[log[-1][1]]
+            prev = [prev] if run["kind"] == "mono" else prev
+            for ch, exp in enumerate(blk["prev"]):
+                assert len(prev[ch]) == exp["length"], what + " prev length"
+                _close(prev[ch], from_bits(exp["data"]), what + " prev")
+        r = run["resumed"]
+        cR = oracle.StubContext([from_bits(b).copy() for b in r["input"]], r["n"], irs, store, log)
+        ret = make(cR, url, **p)(cR)
+        ret = [ret] if run["kind"] == "mono" else ret
+        for ch, exp in enumerate(r["ret"]):
+            _close(ret[ch], from_bits(exp["data"]), "resumed from cached tail")
+        assert [[e[0], e[1], e[2]] for e in log] == [[e[0], e[1], e[2]] for e in run["log"]]
+
+
+def _sources(case):
+    out = []
+    for s in case["sources"]:
+        buf = [from_bits(b).copy() for b in s["buffer"]]
+        if not s["tuple"]:
+            out.append(buf)
+            continue
+        vol = s.get("volume")
+        if isinstance(vol, dict):
+            vol = {"ramp": lambda x: 0.25 + x / 8, "alt": lambda x: -1.3 if (x & 1) else 0.7}[vol["fn"]]
+        out.append((buf, s.get("length"), vol, s.get("offset")))
+    return out
+
+
+def test_g4_mix_buffers_bit_exact(wp):
+    g = load_golden("g4_mix_buffers.json")
+    for case in g["cases"]:
+        target = [from_bits(b).copy() for b in case["target_in"]]
+        ret = wp.mix.mix_buffers(target, *_sources(case))
+        assert ret is target
+        for ch, exp in enumerate(case["target_out"]):
+            assert_bits_equal(target[ch], exp, case["name"] + " ch%d" % ch)
+
+
+def test_mix_vs_oracle_random_shapes(wp, oracle):
+    rng = np.random.default_rng(5)
+    for trial in range(12):
+        tch, tl = int(rng.integers(1, 3)), int(rng.integers(1, 5000))
+        target = [oracle.synth_noise(tl, 900 + trial * 2 + c) for c in range(tch)]
+        sources = []
+        for s in range(int(rng.integers(1, 9))):
+            sch, rl = int(rng.integers(1, 3)), int(rng.integers(1, 7000))
+            buf = [oracle.synth_noise(rl, 2000 + trial * 100 + s * 2 + c) for c in range(sch)]
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                sources.append(buf)
+            else:
+                sources.append((buf, float(rng.choice([1, .5, .75, 2.25, 1 / 3])), float(rng.choice([1, 1.3, 1 / 64, -0.2])),
+                                int(rng.choice([0, 3, 96000, 2 ** 33 + 11, -2]))))
+        a = [t.copy() for t in target]
+        b = [t.copy() for t in target]
+        wp.mix.mix_buffers(a, *sources)
+        oracle.mix_buffers(b, *sources)
+        for ch in range(tch):
+            assert_bits_equal(a[ch], b[ch].view(np.uint32), "trial %d ch %d" % (trial, ch))
+
+
+def test_g5_c1_mono_impulse_convolve(wp, oracle):
+    g = load_golden("g5_config_sized.json")["c1"]
+    ir = oracle.synth_ir(g["M"], g["seed_ir"])
+    x = oracle.synth_noise(g["L"], g["seed_x"])
+    store, log = {}, []
+    c = oracle.StubContext([x], 0, {"ir:c1": [ir]}, store, log)
+    go = wp.impulse.impulse_convolve(c, "ir:c1", -1)
+    y = go(x)
+    assert len(y) == g["out_len"]
+    assert len(store["kernel:ir:c1:44100:-1"]) == g["kernel_len"]
+    err = _close(y[::g["stride"]], from_bits(g["samples"]), "c1 strided samples vs reference JS")
+    st = g["stats"]
+    assert abs(float(y.astype(np.float64).sum()) - st["sum"]) < 1e-3
+    assert abs(float(np.abs(y).max()) - st["max_abs"]) < TOL
+    full = oracle.fft_convolution(g["L"], oracle.fft_process_kernel(g["L"], ir), g["M"])(x)
+    _close(y, full, "c1 every sample vs oracle")
+    assert [[e[0], e[1]] for e in log] == [[e[0], e[1]] for e in g["cache_log"]]
+    print("c1 max abs err vs reference: %.3e" % err)
+
+
+@pytest.mark.parametrize("offset", [0, 1000])
+def test_g5_c2_stereo_reverb_four_bars(wp, oracle, offset):
+    g = load_golden("g5_config_sized.json")["c2_offset%d" % offset]
+    L, M = g["L"], g["M"]
+    irs = {"ir:c2": [oracle.synth_ir(M, s) for s in g["seeds_ir"]]}
+    store, log = {}, []
+    mk = lambda n: oracle.StubContext([oracle.synth_noise(L, s, n) for s in g["seeds_x"]], n, irs, store, log)
+    c0 = mk(0)
+    fn = wp.impulse.impulse_reverb_stereo(c0, "ir:c2", offset=offset, id="c2")
+    for b, bar in enumerate(g["bars"]):
+        c = c0 if b == 0 else mk(b * L)
+        r = fn(c)
+        assert [len(r[0]), len(r[1])] == bar["ret_len"]
+        for ch in range(2):
+            base = r[ch].base
+            assert r[ch].__array_interface__["data"][0] - base.__array_interface__["data"][0] == bar["byte_offset"][ch]
+            assert base.nbytes == bar["buffer_bytes"]
+            _close(r[ch][::bar["stride"]], from_bits(bar["samples"][ch]), "c2 bar %d ch %d" % (b, ch))
+            assert abs(float(np.abs(r[ch]).max()) - bar["stats"][ch]["max_abs"]) < TOL
+    assert [e[1] for e in log if e[0] == "set"] == g["keys"]
+
+
+def test_g5_c3_single_job_full_length(wp, oracle):
+    g = load_golden("g5_config_sized.json")["c3_job0"]
+    ir = oracle.synth_ir(g["M"], g["seed_ir"])
+    x = oracle.synth_noise(g["L"], g["seed_x"])
+    k = wp.convolve.fft_process_kernel(g["L"], ir)
+    y = wp.convolve.fft_convolution(g["L"], k, g["M"])(x)
+    assert len(y) == g["out_len"]
+    _close(y[:64], from_bits(g["head"]), "head")
+    _close(y[-64:], from_bits(g["tail"]), "tail")
+    err = _close(y[::g["stride"]], from_bits(g["samples"]), "strided")
+    print("c3 job max abs err vs reference: %.3e" % err)
+
+
+def test_convolution_properties_full_size(wp, oracle):
+    """Size-independent checks at the 60 s x 2 s-IR job size: linearity, shift,
+    and an impulse input reproducing the IR."""
+    L, M = 2880000, 96000
+    ir = oracle.synth_ir(M, 500001)
+    k = wp.convolve.fft_process_kernel(L, ir)
+    go = wp.convolve.fft_convolution(L, k, M)
+    d = np.zeros(L, np.float32)
+    d[0] = 1.0
+    y = go(d)
+    _close(y[:M], ir, "delta -> IR", tol=1e-6)
+    assert float(np.abs(y[M:]).max()) <= 1e-6
+    d[:] = 0
+    d[L - 1] = 0.5
+    y = go(d)
+    _close(y[L - 1:L - 1 + M], 0.5 * ir, "delayed delta", tol=1e-6)
+    assert float(np.abs(y[:L - 1]).max()) <= 1e-6
+    a, b = oracle.synth_noise(L, 31), oracle.synth_noise(L, 32)
+    ya, yb, yab = go(a), go(b), go((a * 0.5 + b * 0.25).astype(np.float32))
+    _close(yab, 0.5 * ya.astype(np.float64) + 0.25 * yb, "linearity", tol=2e-6)
