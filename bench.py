@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — whole-job throughput of the reverb+mix hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the one the metric's target is quoted on):
+256 independent stereo tracks x 60 s at 48 kHz (F = 2 880 000 frames), each
+channel convolved with a 2 s IR (M = 96 000; one `go` of L = F per channel-job,
+lib/convolve.js:570-583), then all 256 stereo results summed into one stereo
+master bus (src/mix-buffers.js tuple form, vol = 1/256).  One "step" = that
+whole pass.  Inputs are synthetic integer-hash noise already resident in HBM
+when the timed region starts.  With --gpus N each rank owns 256 tracks (weak
+scaling) and the rank-local partial buses are combined by one RCCL reduce.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (≈6300 GB/s measured copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tracks", type=int, default=256, help="stereo tracks per GPU")
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--ir-seconds", type=float, default=2.0)
+    ap.add_argument("--rate", type=int, default=48000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tracks", type=int, default=4, help="stereo tracks in the bounded CPU sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(F, M, tracks):
+    """The oracle (CPU port of the reference algorithm, one thread) on a bounded
+    sample of the same workload: `tracks` stereo tracks of the full length, IR
+    spectra cached as the reference caches them (lib/impulse-convolve-stereo.js:9-17),
+    then the same mix.  Checker code, timed here only as the reported baseline."""
+    import numpy as np
+    from oracle import oracle as o
+    o.build()
+    irs = [o.synth_ir(M, 500000), o.synth_ir(M, 500001)]
+    kern = [o.fft_process_kernel(F, h) for h in irs]
+    gos = [o.fft_convolution(F, k, M) for k in kern]
+    xs = [[o.synth_noise(F, 1000 + 2 * t + ch) for ch in range(2)] for t in range(tracks)]
+    t0 = time.perf_counter()
+    outs = [[gos[ch](xs[t][ch]) for ch in range(2)] for t in range(tracks)]
+    bus = [np.zeros(F, np.float32), np.zeros(F, np.float32)]
+    o.mix_buffers(bus, *[([y[0][:F], y[1][:F]], 1, 1.0 / 256, 0) for y in outs])
+    dt = time.perf_counter() - t0
+    samples = tracks * 2 * (F + M)
+    return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d of 256 stereo tracks, full length (L=%d, M=%d): go() per channel + mixBuffers, "
+                      "IR spectra cached; %.1f s of CPU time" % (tracks, F, M, dt)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from dsp_amd import device as dev
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    F = int(round(a.seconds * a.rate))
+    M = int(round(a.ir_seconds * a.rate))
+    tracks = a.tracks
+    njobs = 2 * tracks
+    out_len = F + M
+    stride_out = (out_len + 3) & ~3
+
+    # ---- resident inputs ----
+    ir_host = torch.from_numpy(__import__("numpy").stack([dev.synth_ir(M, 500000), dev.synth_ir(M, 500001)]))
+    ir = dev.DeviceIR(ir_host.cuda().contiguous(), F)
+    conv = dev.BatchedConvolver(ir, [j % 2 for j in range(njobs)])
+    x = torch.empty((njobs, F), dtype=torch.float32, device="cuda")
+    t_lo, _ = dev.shard_range(tracks * world, rank, world)
+    for j in range(njobs):
+        dev.synth_noise(x[j], 1000 + 2 * (t_lo + j // 2) + (j % 2))
+    out = torch.empty((njobs, stride_out), dtype=torch.float32, device="cuda")
+    bus = torch.zeros((2, F), dtype=torch.float32, device="cuda")
+    mix = dev.DeviceMix([{"ch": [out[2 * t], out[2 * t + 1]], "rl": F, "sl": F, "vol": 1.0 / 256, "o": 0}
+                         for t in range(tracks)])
+    conv.profile(True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    kern_ms = {"k_fft_fwd": 0.0, "k_mac": 0.0, "k_fft_inv": 0.0, "k_mix": 0.0}
+
+    def step(timed):
+        conv.run(x, out)
+        bus.zero_()
+        ev[0].record()
+        mix.run([bus[0], bus[1]])
+        ev[1].record()
+        if world > 1:
+            dev.reduce_master_bus(bus, dist, dst=0)
+        if timed:
+            f, m, i = conv.profile_read()
+            ev[1].synchronize()
+            kern_ms["k_fft_fwd"] += f
+            kern_ms["k_mac"] += m
+            kern_ms["k_fft_inv"] += i
+            kern_ms["k_mix"] += ev[0].elapsed_time(ev[1])
+
+    for _ in range(a.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        K = a.steps
+        total_samples = world * njobs * out_len * K
+        B = capi_info(conv, 2)
+        T = capi_info(conv, 1)
+        Tin = min(T, (F + B - 1) // B + 1)
+        # algorithmic bytes per launch (see DESIGN.md "Kernels and rooflines")
+        alg = {
+            "k_fft_fwd": njobs * (4 * F + 8 * B * Tin),
+            "k_mac": njobs * (8 * B * Tin + 8 * B * T),
+            "k_fft_inv": njobs * (8 * B * T + 4 * out_len),
+            "k_mix": F * (4 * 2 * tracks + 2 * 4 * 2),
+        }
+        avg = {k: v / K for k, v in kern_ms.items()}
+        dom = max(avg, key=avg.get)
+        ach = alg[dom] / (avg[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC bytes per launch from the committed rocprofv3 passes
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "output Msamples/s (whole node) for stereo IR reverb+mix",
+            "value": total_samples / dt / 1e6, "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": a.warmup,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "batched reverb+mix: %d stereo tracks/GPU x %.0f s @ %d Hz x %.0f s stereo IR, "
+                                   "one go() per channel-job then mixBuffers into a stereo bus" % (tracks, a.seconds, a.rate, a.ir_seconds),
+                       "tracks_per_gpu": tracks, "frames": F, "ir_len": M, "partition": B, "blocks": T,
+                       "parallelism": "tracks sharded over %d GPU(s), RCCL reduce of the bus" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": avg,
+                         "kernel_GBs": {k: alg[k] / (avg[k] * 1e-3) / 1e9 for k in avg if avg[k] > 0},
+                         "pipeline_compulsory_GBs": njobs * (4 * F + 4 * out_len) / (dt / K) / 1e9},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(F, M, a.cpu_tracks)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def capi_info(conv, which):
+    from dsp_amd import capi
+    return int(capi.lib().wp_conv_info(conv.handle, which))
+
+
+if __name__ == "__main__":
+    main()

@@ -192,8 +192,9 @@ static int get_tables(int dev, int B, const c32 **out)
         }
         for (int b = 0; b < B / 256; b++)
             h[512 + b] = {(float)cos(2 * pi * b * 256.0 / B), (float)-sin(2 * pi * b * 256.0 / B)};
-        const int wo = table_wsplit_offset(B);
-        for (int q = 0; q < B / 2; q++) h[wo + q] = {(float)cos(pi * q / B), (float)-sin(pi * q / B)};
+        const int ho = table_thalf_offset(B), wo = table_wsplit_offset(B);
+        for (int j = 0; j < 256; j++) h[ho + j] = {(float)cos(pi * j / B), (float)-sin(pi * j / B)};
+        for (int q = 0; q < B; q++) h[wo + q] = {(float)cos(pi * (q + 0.5) / B), (float)-sin(pi * (q + 0.5) / B)};
         DevTables t;
         HIPCHK(hipMalloc((void **)&t.d, sizeof(c32) * n));
         HIPCHK(hipMemcpy(t.d, h.data(), sizeof(c32) * n, hipMemcpyHostToDevice));
@@ -209,7 +210,7 @@ struct wp_ir {
     int nch;
     int64_t M, L;
     int B, P, Pp, PG;
-    float4 *Hp;        // [nch][Pp][B/2]
+    c32 *Hp;           // [nch][Pp][B] per-bin partition spectra
     const c32 *tables;
     int64_t bytes;
     wp_conv *single;   // lazily built 1-job plan for wp_convolve
@@ -224,6 +225,9 @@ struct wp_conv {
     int32_t *job_irch;  // device
     c32 *Z, *W;
     int64_t bytes;
+    bool prof;
+    bool prof_valid;
+    hipEvent_t ev[4];
 };
 
 struct wp_reverb {
@@ -242,7 +246,7 @@ static int choose_B(int64_t L, int64_t M)
 {
     if (const char *e = getenv("WPDSP_B")) {
         const int b = atoi(e);
-        if (b == 1024 || b == 2048 || b == 4096 || b == 8192) return b;
+        if (b == 1024 || b == 2048 || b == 4096) return b;
     }
     return (L + M <= 8192) ? 1024 : 4096;
 }
@@ -292,7 +296,7 @@ static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, 
         delete ir;
         return nullptr;
     }
-    const size_t hbytes = sizeof(float4) * (size_t)nch * ir->Pp * (ir->B / 2);
+    const size_t hbytes = sizeof(c32) * (size_t)nch * ir->Pp * ir->B;
     hipError_t e;
     if ((e = hipMalloc((void **)&ir->Hp, hbytes)) != hipSuccess) return bail("hipMalloc(Hp)", e);
     if ((e = hipMemsetAsync(ir->Hp, 0, hbytes, s)) != hipSuccess) return bail("hipMemsetAsync", e);
@@ -399,7 +403,7 @@ extern "C" wp_conv *wp_conv_create(wp_ir *ir, int njobs, const int32_t *job_ch)
     c->T = (int)((ir->L + ir->M + ir->B - 1) / ir->B);
     // time chunks: enough threads to fill the chip when there are few jobs
     {
-        const int64_t per_job = ir->B / 2;
+        const int64_t per_job = ir->B;
         int64_t want = (256 * 8 * 64 + per_job * njobs - 1) / (per_job * njobs);
         int64_t maxchunks = c->T / (2 * ir->PG);
         if (maxchunks < 1) maxchunks = 1;
@@ -409,6 +413,8 @@ extern "C" wp_conv *wp_conv_create(wp_ir *ir, int njobs, const int32_t *job_ch)
     }
     c->job_irch = nullptr;
     c->Z = c->W = nullptr;
+    c->prof = c->prof_valid = false;
+    for (auto &e : c->ev) e = nullptr;
     const size_t sbytes = sizeof(c32) * (size_t)njobs * c->T * ir->B;
     hipError_t e = hipMalloc((void **)&c->job_irch, sizeof(int32_t) * njobs);
     if (e == hipSuccess) e = hipMemcpy(c->job_irch, job_ch, sizeof(int32_t) * njobs, hipMemcpyHostToDevice);
@@ -429,10 +435,46 @@ extern "C" void wp_conv_destroy(wp_conv *c)
     if (c->job_irch) (void)hipFree(c->job_irch);
     if (c->Z) (void)hipFree(c->Z);
     if (c->W) (void)hipFree(c->W);
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
 extern "C" int64_t wp_conv_workspace_bytes(const wp_conv *c) { return c ? c->bytes : WP_ERR_INVALID; }
+
+extern "C" int64_t wp_conv_info(const wp_conv *c, int which)
+{
+    if (!c) return WP_ERR_INVALID;
+    switch (which) {
+    case 0: return c->njobs;
+    case 1: return c->T;
+    case 2: return c->ir->B;
+    case 3: return c->ir->Pp;
+    case 4: return c->tchunk;
+    }
+    return WP_ERR_INVALID;
+}
+
+extern "C" int wp_conv_profile(wp_conv *c, int enable)
+{
+    if (int rc = need_device()) return rc;
+    if (!c) return fail(WP_ERR_INVALID, "wp_conv_profile: null plan");
+    if (enable && !c->ev[0])
+        for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
+    c->prof = enable != 0;
+    c->prof_valid = false;
+    return WP_OK;
+}
+
+extern "C" int wp_conv_profile_read(wp_conv *c, float *ms3)
+{
+    if (int rc = need_device()) return rc;
+    if (!c || !ms3) return fail(WP_ERR_INVALID, "wp_conv_profile_read: null argument");
+    if (!c->prof || !c->prof_valid) return fail(WP_ERR_INVALID, "wp_conv_profile_read: no profiled run recorded");
+    HIPCHK(hipEventSynchronize(c->ev[3]));
+    for (int i = 0; i < 3; i++) HIPCHK(hipEventElapsedTime(&ms3[i], c->ev[i], c->ev[i + 1]));
+    return WP_OK;
+}
 
 static int check_in_len(const wp_ir *ir, int64_t in_len)
 {
@@ -457,12 +499,22 @@ extern "C" int wp_conv_run_dev(wp_conv *c, const float *in_dev, int64_t in_strid
     int Tin = (int)((in_len + B - 1) / B) + 1;
     if (Tin > T) Tin = T;
     if (in_len == 0) Tin = 0;
+    if (c->prof) HIPCHK(hipEventRecord(c->ev[0], s));
     if (Tin > 0) HIPCHK(launch_fft_fwd(B, false, in_dev, in_stride, in_len, c->Z, T, Tin, c->njobs, ir->tables, s));
-    HIPCHK(launch_mac(ir->PG, c->Z, c->W, ir->Hp, ir->tables + table_wsplit_offset(B), c->job_irch, B, T, Tin, ir->Pp,
-                      c->njobs, c->tchunk, s));
+    if (c->prof) HIPCHK(hipEventRecord(c->ev[1], s));
+    if (Tin == 0)  // no input at all: the result is L+M zeros
+        HIPCHK(hipMemsetAsync(c->W, 0, sizeof(c32) * (size_t)c->njobs * T * B, s));
+    else
+        HIPCHK(launch_mac(ir->PG, c->Z, c->W, ir->Hp, ir->tables + table_wsplit_offset(B), c->job_irch, B, T, Tin, ir->Pp,
+                          c->njobs, c->tchunk, s));
+    if (c->prof) HIPCHK(hipEventRecord(c->ev[2], s));
     if (prev_dev && prev_len > ir->L + ir->M) prev_len = ir->L + ir->M;
     HIPCHK(launch_fft_inv(B, c->W, T, c->njobs, out_dev, out_stride, ir->L + ir->M, prev_len > 0 ? prev_dev : nullptr,
                           prev_stride, prev_len, ir->tables, s));
+    if (c->prof) {
+        HIPCHK(hipEventRecord(c->ev[3], s));
+        c->prof_valid = true;
+    }
     return WP_OK;
 }
 
@@ -633,7 +685,7 @@ extern "C" int wp_mix_dev(float *const *tgt_dev, int tch, int64_t tl, const wp_s
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     const size_t src_bytes = (sizeof(wp_src) * (size_t)nsrc + 255) & ~(size_t)255;
-    const size_t bytes = src_bytes + mix_desc_bytes() * (size_t)nsrc;
+    const size_t bytes = src_bytes + mix_scratch_bytes(nsrc);
     void *scr = nullptr;
     if (int rc = mix_scratch(dev, bytes, s, &scr)) return rc;
     const wp_src *sd = srcs;

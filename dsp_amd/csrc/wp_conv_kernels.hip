@@ -83,6 +83,7 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_fwd(const float *__r
             return r;
         });
     }
+    pre_twist<B>(tid, v, tables + table_thalf_offset(B));
     middle_stages<B, false>(tid, v, lds, tw);
     c32 *z = Z + ((int64_t)job * T + t) * B;
     stage_store<B, 2, false>(tid, v, [&](int i, c32 val, int) { z[i] = val; });
@@ -119,8 +120,10 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv(const c32 *__res
     const bool fast = (o0 + B <= out_len) && ((reinterpret_cast<uintptr_t>(y + o0) & 7) == 0) &&
                       (!pv || prev_len <= o0 || (o0 + B <= prev_len && (reinterpret_cast<uintptr_t>(pv + o0) & 7) == 0));
     const bool addp = pv && o0 + B <= prev_len;
+    const c32 *thalf = tables + table_thalf_offset(B);
     stage_store<B, 2, true>(tid, v, [&](int i, c32 val, auto tt) {
         if constexpr (int(tt) >= R / 2) {  // only the second half of the block is output
+            val = post_twist<B, int(tt)>(val, thalf[i & (B / R - 1)]);
             const int64_t o = o0 + 2 * (int64_t)(i - B / 2);
             if (fast) {
                 if (addp) {
@@ -138,117 +141,130 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv(const c32 *__res
 }
 
 // ---------------------------------------------------------------------------
-// IR partition spectra -> paired layout, scaled by 1/(8B) so that the MAC needs
-// no normalisation: Hp[(irch*Pp + p)*(B/2) + q] = (H[q], H[B-q]) for q >= 1 and
-// ((H[0], H[B]), H[B/2]) for q == 0, H = R_h / (4B).
-__global__ void k_hpack(const c32 *__restrict__ Zir, float4 *__restrict__ Hp, const c32 *__restrict__ wsplit,
-                        int B, int P, int Pp)
+// lane layout shared by k_hpack and k_mac: a wavefront owns 32 bin pairs; lanes
+// 0-31 hold bins q = 32*wave + lane, lanes 32-63 hold their partners B-1-q, so
+// the partner of a lane is lane ^ 32 and each half of a wave accesses one
+// 256-byte aligned run.
+__device__ __forceinline__ int lane_bin(int slot, int B)
 {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= B / 2) return;
+    const int q = ((slot >> 6) << 5) + (slot & 31);
+    return (slot & 32) ? B - 1 - q : q;
+}
+
+// IR partition spectra -> per-bin layout, scaled by 1/(8B) so that the MAC needs
+// no normalisation: Hc[(irch*Pp + p)*B + k] = R_h[k]/(4B).
+__global__ void k_hpack(const c32 *__restrict__ Zir, c32 *__restrict__ Hc, const c32 *__restrict__ wbin, int B, int P,
+                        int Pp)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= B) return;
     const int p = blockIdx.y, ch = blockIdx.z;
     const c32 *z = Zir + ((int64_t)ch * P + p) * B;
-    c32 rk, rm;
-    if (q == 0) split_q0(z[0], z[B / 2], rk, rm);
-    else split_pair(z[q], z[B - q], wsplit[q], rk, rm);
+    const c32 r = bin_split(z[k], z[B - 1 - k], wbin[k]);
     const float s = 1.0f / (8.0f * (float)B);
-    Hp[((int64_t)ch * Pp + p) * (B / 2) + q] = make_float4(rk.x * s, rk.y * s, rm.x * s, rm.y * s);
+    Hc[((int64_t)ch * Pp + p) * B + k] = c32{r.x * s, r.y * s};
 }
+
+// loads in flight per lane in k_mac (must divide PG so ring slots stay static)
+#ifndef WP_MAC_DEPTH
+#define WP_MAC_DEPTH(PG) ((PG) <= 12 ? (PG) : 8)
+#endif
 
 // ---------------------------------------------------------------------------
 // Spectral multiply-accumulate across IR partitions (frequency-domain delay
-// line held in registers).  Thread q owns bins q and B-q of one job for a run
-// of output blocks [ta, tb); it streams Z[tau] once, keeps PG running sums
-// (one per in-flight output block) and the PG partition spectra in VGPRs:
-//   acc[(i+p) % PG] += split(Z[tau]) * H[p0+p]        for p < PG
-// and emits W[t] when the sum for t = tau + p0 is complete.
+// line held in registers).  A lane owns ONE bin of one job for a run of output
+// blocks [ta, tb): it streams Z[tau] once, keeps PG running sums (one per
+// in-flight output block) and the PG partition spectra of its bin in VGPRs,
+//   acc[(i+p) % PG] += split(Z[tau]) * H[p0+p]        for p < PG,
+// and emits W[t] when the sum for t = tau + p0 is complete.  The real/packed
+// spectrum conversion needs the mirrored bin, which lives in lane ^ 32.
+//
+// Every load in the steady-state loop is unconditional (out-of-range blocks
+// read a clamped address and are zeroed by a select) and every store is
+// unconditional, so the compiler can count outstanding memory operations and
+// wait with vmcnt(N) instead of draining the queue each iteration.
 template <int PG, bool ACCUM>
 __global__ __launch_bounds__(256) void k_mac(const c32 *__restrict__ Z, c32 *__restrict__ W,
-                                             const float4 *__restrict__ Hp, const c32 *__restrict__ wsplit,
+                                             const c32 *__restrict__ Hc, const c32 *__restrict__ wbin,
                                              const int32_t *__restrict__ job_irch, int B, int T, int Tin, int Pp,
                                              int p0, int tchunk)
 {
-    constexpr int D = 4;  // prefetch depth (loads in flight per thread)
+    constexpr int D = WP_MAC_DEPTH(PG);
     static_assert(PG % D == 0, "ring");
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    const int half = B >> 1;
-    if (q >= half) return;
+    const int slot = blockIdx.x * 256 + threadIdx.x;  // grid.x * 256 == B
+    const int k = lane_bin(slot, B);
     const int job = blockIdx.y;
     const int ta = blockIdx.z * tchunk;
     const int tb = (ta + tchunk < T) ? ta + tchunk : T;
-    const bool is0 = (q == 0);
-    const int km = is0 ? half : B - q;
-    const c32 w = wsplit[q];
+    const c32 w = wbin[k];
     const int irch = job_irch[job];
 
-    float4 h[PG];
+    c32 h[PG];
     {
-        const float4 *hp = Hp + ((int64_t)irch * Pp + p0) * half + q;
+        const c32 *hp = Hc + ((int64_t)irch * Pp + p0) * B + k;
 #pragma unroll
-        for (int p = 0; p < PG; p++) h[p] = hp[(int64_t)p * half];
+        for (int p = 0; p < PG; p++) h[p] = hp[(int64_t)p * B];
     }
-    const c32 *zj = Z + (int64_t)job * T * B;
-    c32 *wj = W + (int64_t)job * T * B;
+    const c32 *zj = Z + (int64_t)job * T * B + k;
+    c32 *wj = W + (int64_t)job * T * B + k;
 
-    c32 ak[PG], am[PG];
+    c32 acc[PG];
 #pragma unroll
-    for (int p = 0; p < PG; p++) ak[p] = am[p] = c32{0.f, 0.f};
+    for (int p = 0; p < PG; p++) acc[p] = c32{0.f, 0.f};
 
+    // step i consumes input block tau0 + i and completes output block tau0 + i + p0
     const int tau0 = ta - p0 - (PG - 1);
     const int nsteps = (tb - ta) + (PG - 1);
-    auto ld = [&](int i, c32 &a, c32 &b) {
+    const int tin_last = Tin - 1;  // Tin >= 1 (the host launches a memset instead when there is no input)
+    auto ld = [&](int i) {         // unconditional: clamped address, zero-selected value
         const int tau = tau0 + i;
-        if (i < nsteps && tau >= 0 && tau < Tin) {
-            const c32 *z = zj + (int64_t)tau * B;
-            a = z[q];
-            b = z[km];
-        } else {
-            a = b = c32{0.f, 0.f};
+        const int tc = tau < 0 ? 0 : (tau > tin_last ? tin_last : tau);
+        c32 a = zj[(int64_t)tc * B];
+        const bool ok = (tau == tc);
+        a.x = ok ? a.x : 0.0f;
+        a.y = ok ? a.y : 0.0f;
+        return a;
+    };
+    c32 ring[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) ring[d] = ld(d);
+
+    // one step; SLOT = i % PG.  STORE: 0 never (warm-up), 1 always, 2 if i < nsteps
+    auto step = [&](int i, auto slot_c, auto store_c) {
+        constexpr int u = decltype(slot_c)::value;
+        constexpr int STORE = decltype(store_c)::value;
+        constexpr int rs = u % D;
+        const c32 z = ring[rs];
+        ring[rs] = ld(i + D);
+        const c32 zp = {__shfl_xor(z.x, 32), __shfl_xor(z.y, 32)};
+        const c32 x = bin_split(z, zp, w);
+        static_for<0, PG>([&](auto p) {
+            constexpr int s = (u + int(p)) % PG;
+            acc[s].x = fmaf(-x.y, h[p].y, fmaf(x.x, h[p].x, acc[s].x));
+            acc[s].y = fmaf(x.y, h[p].x, fmaf(x.x, h[p].y, acc[s].y));
+        });
+        const c32 y = acc[u];
+        acc[u] = c32{0.f, 0.f};
+        if constexpr (STORE != 0) {
+            const c32 yp = {__shfl_xor(y.x, 32), __shfl_xor(y.y, 32)};
+            c32 o = bin_unsplit(y, yp, w);
+            if (STORE == 1 || i < nsteps) {
+                c32 *wo = wj + (int64_t)(tau0 + i + p0) * B;
+                if (ACCUM) o = o + *wo;
+                *wo = o;
+            }
         }
     };
-    c32 rk_[D], rm_[D];
-#pragma unroll
-    for (int d = 0; d < D; d++) ld(d, rk_[d], rm_[d]);
 
-    for (int i0 = 0; i0 < nsteps; i0 += PG) {
-        static_for<0, PG>([&](auto u) {
-            const int i = i0 + u;
-            if (i < nsteps) {
-                constexpr int slot = int(u) % D;
-                const c32 zk = rk_[slot], zm = rm_[slot];
-                ld(i + D, rk_[slot], rm_[slot]);
-                c32 xk, xm;
-                if (is0) split_q0(zk, zm, xk, xm);
-                else split_pair(zk, zm, w, xk, xm);
-                // slot k of thread 0 holds two real bins: elementwise product
-                const float xa = is0 ? xk.y : xk.x;
-                const float xb = is0 ? 0.0f : xk.y;
-                static_for<0, PG>([&](auto p) {
-                    constexpr int s = (int(u) + int(p)) % PG;
-                    const float4 hh = h[p];
-                    ak[s].x += xk.x * hh.x - xb * hh.y;
-                    ak[s].y += xa * hh.y + xb * hh.x;
-                    am[s].x += xm.x * hh.z - xm.y * hh.w;
-                    am[s].y += xm.x * hh.w + xm.y * hh.z;
-                });
-                const int t = tau0 + i + p0;
-                if (i >= PG - 1) {  // t in [ta, tb)
-                    c32 ok, om;
-                    if (is0) unsplit_q0(ak[u], am[u], ok, om);
-                    else unsplit_pair(ak[u], am[u], w, ok, om);
-                    c32 *wo = wj + (int64_t)t * B;
-                    if (ACCUM) {
-                        const c32 a = wo[q], b = wo[km];
-                        ok = ok + a;
-                        om = om + b;
-                    }
-                    wo[q] = ok;
-                    wo[km] = om;
-                }
-                ak[u] = am[u] = c32{0.f, 0.f};
-            }
-        });
-    }
+    // warm-up: the first PG-1 steps only fill the delay line
+    static_for<0, PG - 1>([&](auto u) { step(int(u), u, ic<0>{}); });
+    // steady state: whole blocks of PG steps, everything unconditional
+    int i = PG - 1;
+    for (; i + PG <= nsteps; i += PG)
+        static_for<0, PG>([&](auto j) { step(i + j, ic<(PG - 1 + int(j)) % PG>{}, ic<1>{}); });
+    // remainder (fewer than PG steps): stores guarded
+    if (i < nsteps)
+        static_for<0, PG - 1>([&](auto j) { step(i + j, ic<(PG - 1 + int(j)) % PG>{}, ic<2>{}); });
 }
 
 // ---------------------------------------------------------------------------
@@ -283,7 +299,6 @@ hipError_t launch_fft_fwd(int B, bool irmode, const float *in, int64_t in_stride
     case 1024: return launch_fwd_t<1024>(irmode, in, in_stride, in_len, Z, T, nblocks, njobs, tables, s);
     case 2048: return launch_fwd_t<2048>(irmode, in, in_stride, in_len, Z, T, nblocks, njobs, tables, s);
     case 4096: return launch_fwd_t<4096>(irmode, in, in_stride, in_len, Z, T, nblocks, njobs, tables, s);
-    case 8192: return launch_fwd_t<8192>(irmode, in, in_stride, in_len, Z, T, nblocks, njobs, tables, s);
     }
     return hipErrorInvalidValue;
 }
@@ -310,24 +325,23 @@ hipError_t launch_fft_inv(int B, const c32 *W, int T, int njobs, float *out, int
     case 1024: return launch_inv_t<1024>(W, T, njobs, out, out_stride, out_len, prev, prev_stride, prev_len, tables, s);
     case 2048: return launch_inv_t<2048>(W, T, njobs, out, out_stride, out_len, prev, prev_stride, prev_len, tables, s);
     case 4096: return launch_inv_t<4096>(W, T, njobs, out, out_stride, out_len, prev, prev_stride, prev_len, tables, s);
-    case 8192: return launch_inv_t<8192>(W, T, njobs, out, out_stride, out_len, prev, prev_stride, prev_len, tables, s);
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_hpack(const c32 *Zir, float4 *Hp, const c32 *wsplit, int B, int P, int Pp, int nch, hipStream_t s)
+hipError_t launch_hpack(const c32 *Zir, c32 *Hc, const c32 *wbin, int B, int P, int Pp, int nch, hipStream_t s)
 {
-    const dim3 grid((B / 2 + 255) / 256, P, nch), block(256);
-    hipLaunchKernelGGL(k_hpack, grid, block, 0, s, Zir, Hp, wsplit, B, P, Pp);
+    const dim3 grid(B / 256, P, nch), block(256);
+    hipLaunchKernelGGL(k_hpack, grid, block, 0, s, Zir, Hc, wbin, B, P, Pp);
     return hipGetLastError();
 }
 
 template <int PG>
-static hipError_t launch_mac_t(const c32 *Z, c32 *W, const float4 *Hp, const c32 *wsplit, const int32_t *job_irch,
+static hipError_t launch_mac_t(const c32 *Z, c32 *W, const c32 *Hp, const c32 *wsplit, const int32_t *job_irch,
                                int B, int T, int Tin, int Pp, int njobs, int tchunk, hipStream_t s)
 {
     const int nchunks = (T + tchunk - 1) / tchunk;
-    const dim3 grid((B / 2) / 256, njobs, nchunks), block(256);
+    const dim3 grid(B / 256, njobs, nchunks), block(256);
     for (int p0 = 0; p0 < Pp; p0 += PG) {
         if (p0 == 0)
             hipLaunchKernelGGL((k_mac<PG, false>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tin, Pp, p0, tchunk);
@@ -337,7 +351,7 @@ static hipError_t launch_mac_t(const c32 *Z, c32 *W, const float4 *Hp, const c32
     return hipGetLastError();
 }
 
-hipError_t launch_mac(int PG, const c32 *Z, c32 *W, const float4 *Hp, const c32 *wsplit, const int32_t *job_irch,
+hipError_t launch_mac(int PG, const c32 *Z, c32 *W, const c32 *Hp, const c32 *wsplit, const int32_t *job_irch,
                       int B, int T, int Tin, int Pp, int njobs, int tchunk, hipStream_t s)
 {
     switch (PG) {

@@ -143,11 +143,6 @@ struct FftPlan<4096> {
     static constexpr int PT = 16, NSTAGE = 3;
     static constexpr int radix(int) { return 16; }
 };
-template <>
-struct FftPlan<8192> {
-    static constexpr int PT = 32, NSTAGE = 3;
-    static constexpr int radix(int s) { return s == 0 ? 32 : 16; }
-};
 template <int B>
 constexpr int plan_ns(int s)  // product of the radices before stage s
 {
@@ -175,7 +170,7 @@ struct TwTables {
     const c32 *thi;
 };
 template <int B>
-constexpr int tw_table_points() { return 256 + 256 + B / 256; }
+constexpr int tw_table_points() { return 256 + 256 + B / 256; }  // + thalf[256] + wbin[B] follow in the device block
 
 template <int B, int NT_TW /* Ns*R of the stage */, bool INV>
 WP_HD c32 stage_twiddle(const TwTables<B> &tw, int m /* t*k < NT_TW */)
@@ -234,43 +229,59 @@ WP_HD void stage_store(int tid, const c32 *v, Dst &&dst)
 }
 
 // ---------------------------------------------------------------------------
-// Real <-> packed-complex spectrum algebra used by the spectral MAC.
-// z[n] = r[2n] + i r[2n+1], Z = FFT_B(z), w = exp(-i*pi*q/B), 1 <= q < B/2:
-//   2*R[q]   = A + w*D,  2*R[B-q] = conj(A - w*D)
-//   A = Z[q] + conj(Z[B-q]),  D = -i*(Z[q] - conj(Z[B-q]))
-// and back (Y Hermitian spectrum -> packed spectrum of the real signal):
-//   2*Z'[q] = A' + E,  2*Z'[B-q] = conj(A' - E)
-//   A' = Y[q] + conj(Y[B-q]),  E = i*conj(w)*(Y[q] - conj(Y[B-q]))
-WP_HD void split_pair(c32 zk, c32 zm, c32 w, c32 &rk, c32 &rm)
+// Odd-frequency ("half-bin shifted") transform of a real 2B-sample segment via
+// one B-point complex FFT.
+//
+//   z[m]  = (r[2m] + i r[2m+1]) * exp(-i*pi*m/B)          (pre-twist)
+//   Z     = FFT_B(z)            = odd-frequency DFT of the packed sequence
+//   2R[k] = (Z[k] + conj(Z[B-1-k])) - i*w_k*(Z[k] - conj(Z[B-1-k])),
+//           w_k = exp(-i*pi*(k+1/2)/B),   k = 0..B-1
+// R[k] = sum_n r[n] exp(-2*pi*i*n*(k+1/2)/(2B)) are the B independent bins of
+// the odd-frequency DFT of the real segment (R[2B-1-k] = conj(R[k])).  Products
+// of such spectra give a negacyclic convolution, whose second half equals the
+// linear convolution exactly as the cyclic one's does, so overlap-save works
+// unchanged.  Compared with the ordinary real FFT this has no DC/Nyquist
+// special bins and, more importantly, bin k pairs with bin B-1-k: a run of 32
+// bins and the run of their partners are both 256-byte aligned in memory.
+//
+// Back: 2Z'[k] = (Y[k] + conj(Y[B-1-k])) + i*conj(w_k)*(Y[k] - conj(Y[B-1-k])),
+//       r[2m] + i r[2m+1] = IFFT_B(Z')[m] * exp(+i*pi*m/B)  (post-twist)
+WP_HD c32 bin_split(c32 z, c32 zp, c32 w)
 {
-    const c32 A = {zk.x + zm.x, zk.y - zm.y};
-    const c32 D = {zk.y + zm.y, zm.x - zk.x};
-    const c32 wd = cmul(w, D);
-    rk = A + wd;
-    rm = cconj(A - wd);
+    const c32 A = {z.x + zp.x, z.y - zp.y};
+    const c32 D = {z.x - zp.x, z.y + zp.y};
+    const c32 t = cmul(w, D);
+    return {A.x + t.y, A.y - t.x};
 }
-WP_HD void unsplit_pair(c32 yk, c32 ym, c32 w, c32 &zk, c32 &zm)
+WP_HD c32 bin_unsplit(c32 y, c32 yp, c32 w)
 {
-    const c32 A = {yk.x + ym.x, yk.y - ym.y};
-    const float dx = yk.x - ym.x, dy = yk.y + ym.y;
-    // i*conj(w) = (w.y, w.x) * ... : conj(w) = (w.x, -w.y); i*(a+ib) = (-b, a)
-    const c32 iw = {w.y, w.x};
-    const c32 E = {iw.x * dx - iw.y * dy, iw.x * dy + iw.y * dx};
-    zk = A + E;
-    zm = cconj(A - E);
+    const c32 A = {y.x + yp.x, y.y - yp.y};
+    const float dx = y.x - yp.x, dy = y.y + yp.y;
+    return {A.x + (w.y * dx - w.x * dy), A.y + (w.y * dy + w.x * dx)};
 }
-// q == 0 carries the two real bins (DC, Nyquist) in slot k and bin B/2 in slot m:
-//   slot k: (2R[0], 2R[B]) = (2(Zr+Zi), 2(Zr-Zi));   slot m: 2R[B/2] = 2 conj(Z[B/2])
-WP_HD void split_q0(c32 z0, c32 zh, c32 &rk, c32 &rm)
+
+// pre-twist of stage-0 inputs: v[u*R+t] *= thalf_j * exp(-i*pi*t/R) with
+// thalf_j = exp(-i*pi*j/B), j = tid + u*NT  (input index n = j + t*B/R)
+template <int B>
+WP_HD void pre_twist(int tid, c32 *v, const c32 *thalf)
 {
-    rk = {2.0f * (z0.x + z0.y), 2.0f * (z0.x - z0.y)};
-    rm = {2.0f * zh.x, -2.0f * zh.y};
+    constexpr int PT = FftPlan<B>::PT, R = FftPlan<B>::radix(0), NT = B / PT, NB = PT / R;
+    static_assert(R == 16 || R == 8 || R == 4, "stage-0 radix");
+    static_for<0, NB>([&](auto u) {
+        const c32 c = thalf[tid + u * NT];
+        static_for<0, R>([&](auto t) {
+            v[u * R + t] = cmul(v[u * R + t], mul_w32<int(t) * (16 / R), false>(c));
+        });
+    });
 }
-//   2Z'[0] = (Y0 + YB) + i (Y0 - YB);   2Z'[B/2] = 2 conj(Y[B/2])
-WP_HD void unsplit_q0(c32 yk, c32 ym, c32 &z0, c32 &zh)
+// post-twist factor of the last stage's output t of butterfly j (output index
+// i = j + t*B/R): conj(thalf_j) * exp(+i*pi*t/R)
+template <int B, int T_>
+WP_HD c32 post_twist(c32 val, c32 thalf_j)
 {
-    z0 = {yk.x + yk.y, yk.x - yk.y};
-    zh = {2.0f * ym.x, -2.0f * ym.y};
+    constexpr int R = FftPlan<B>::radix(FftPlan<B>::NSTAGE - 1);
+    static_assert(R == 16 || R == 8 || R == 4, "last-stage radix");
+    return cmul(val, mul_w32<T_ * (16 / R), true>(cconj(thalf_j)));
 }
 
 }  // namespace wp

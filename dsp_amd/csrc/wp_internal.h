@@ -16,20 +16,22 @@ constexpr size_t fft_lds_bytes()
 }
 
 // device table block for one partition size B:
-//   [0,256) t256 | [256,512) tlo | [512, 512+B/256) thi | then wsplit[B/2] = exp(-i*pi*q/B)
-inline int table_wsplit_offset(int B) { return 512 + B / 256; }
-inline int table_total_points(int B) { return 512 + B / 256 + B / 2; }
+//   [0,256) t256 | [256,512) tlo | [512, 512+B/256) thi
+//   | thalf[256] = exp(-i*pi*j/B) | wbin[B] = exp(-i*pi*(k+1/2)/B)
+__host__ __device__ inline int table_thalf_offset(int B) { return 512 + B / 256; }
+__host__ __device__ inline int table_wsplit_offset(int B) { return 512 + B / 256 + 256; }
+inline int table_total_points(int B) { return 512 + B / 256 + 256 + B; }
 
 hipError_t launch_fft_fwd(int B, bool irmode, const float *in, int64_t in_stride, int64_t in_len, c32 *Z, int T,
                           int nblocks, int njobs, const c32 *tables, hipStream_t s);
 hipError_t launch_fft_inv(int B, const c32 *W, int T, int njobs, float *out, int64_t out_stride, int64_t out_len,
                           const float *prev, int64_t prev_stride, int64_t prev_len, const c32 *tables, hipStream_t s);
-hipError_t launch_hpack(const c32 *Zir, float4 *Hp, const c32 *wsplit, int B, int P, int Pp, int nch, hipStream_t s);
-hipError_t launch_mac(int PG, const c32 *Z, c32 *W, const float4 *Hp, const c32 *wsplit, const int32_t *job_irch,
+hipError_t launch_hpack(const c32 *Zir, c32 *Hc, const c32 *wbin, int B, int P, int Pp, int nch, hipStream_t s);
+hipError_t launch_mac(int PG, const c32 *Z, c32 *W, const c32 *Hc, const c32 *wbin, const int32_t *job_irch,
                       int B, int T, int Tin, int Pp, int njobs, int tchunk, hipStream_t s);
 
-size_t mix_desc_bytes();  // bytes of device scratch launch_mix needs per source
-hipError_t launch_mix(float *t0, float *t1, int tch, int64_t tl, const wp_src *srcs_dev, void *desc_scratch,
+size_t mix_scratch_bytes(int64_t nsrc);  // bytes of device scratch launch_mix needs
+hipError_t launch_mix(float *t0, float *t1, int tch, int64_t tl, const wp_src *srcs_dev, void *scratch,
                       int64_t nsrc, hipStream_t s);
 hipError_t launch_synth_noise(float *out, int64_t n, uint32_t seed, int64_t start, hipStream_t s);
 

@@ -31,55 +31,68 @@ struct mix_desc {
     int32_t nch;
     int32_t mode;  // 0 skip, 1 every sample NaN, 2 contiguous, 3 general modular indexing
 };
+// first record of the scratch area: what k_mix_prep found out about the whole call
+struct mix_head {
+    int32_t all_fast;  // every source contiguous with a constant gain
+    int32_t pad[3];
+};
 
 enum { MIX_SKIP = 0, MIX_NAN = 1, MIX_CONTIG = 2, MIX_GENERAL = 3 };
 
-// src/mix-buffers.js:5-14 decoded once per source (one thread each).
-__global__ void k_mix_prep(const wp_src *__restrict__ srcs, mix_desc *__restrict__ out, int64_t nsrc, int64_t tl,
-                           int tch)
+// the device pointers inside a descriptor are global memory: saying so lets the
+// compiler emit global_load (vmcnt only) instead of flat_load
+typedef const float __attribute__((address_space(1))) *gf32;
+typedef const double __attribute__((address_space(1))) *gf64;
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef const f4u __attribute__((address_space(1))) *gf4u;
+
+// src/mix-buffers.js:5-14 decoded once per source; one workgroup walks the table.
+__global__ __launch_bounds__(256) void k_mix_prep(const wp_src *__restrict__ srcs, mix_head *__restrict__ head,
+                                                  mix_desc *__restrict__ out, int64_t nsrc, int64_t tl, int tch)
 {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nsrc) return;
-    const wp_src S = srcs[s];
-    mix_desc d;
-    d.ch0 = S.ch[0];
-    d.ch1 = S.nch == 2 ? S.ch[1] : S.ch[0];
-    d.vol_vec = S.vol_vec;
-    d.vol = S.vol;
-    d.rl = S.rl;
-    d.asl = S.sl < 0 ? -S.sl : S.sl;
-    d.o = S.o;
-    d.base = 0;
-    d.nch = S.nch;
-    if ((S.nch != 1 && S.nch != 2) || (tch != 1 && tch != 2)) {
-        d.mode = MIX_SKIP;  // the reference silently ignores other layouts (:18-44, :47-69)
-    } else if (d.asl == 0 || S.rl <= 0) {
-        d.mode = MIX_NAN;   // x % 0 is NaN -> undefined -> NaN
-    } else {
-        d.mode = MIX_GENERAL;
-        if (S.o >= 0) {
-            const int64_t om = S.o % d.asl;
-            if (om + tl <= d.asl && om + tl <= S.rl) {
-                d.mode = MIX_CONTIG;
-                d.base = om;
+    int fast = 1;
+    for (int64_t s = threadIdx.x; s < nsrc; s += 256) {
+        const wp_src S = srcs[s];
+        mix_desc d;
+        d.ch0 = S.ch[0];
+        d.ch1 = S.nch == 2 ? S.ch[1] : S.ch[0];
+        d.vol_vec = S.vol_vec;
+        d.vol = S.vol;
+        d.rl = S.rl;
+        d.asl = S.sl < 0 ? -S.sl : S.sl;
+        d.o = S.o;
+        d.base = 0;
+        d.nch = S.nch;
+        if ((S.nch != 1 && S.nch != 2) || (tch != 1 && tch != 2)) {
+            d.mode = MIX_SKIP;  // the reference silently ignores other layouts (:18-44, :47-69)
+        } else if (d.asl == 0 || S.rl <= 0) {
+            d.mode = MIX_NAN;   // x % 0 is NaN -> undefined -> NaN
+        } else {
+            d.mode = MIX_GENERAL;
+            if (S.o >= 0) {
+                const int64_t om = S.o % d.asl;
+                if (om + tl <= d.asl && om + tl <= S.rl) {
+                    d.mode = MIX_CONTIG;
+                    d.base = om;
+                }
             }
         }
+        if (d.mode != MIX_CONTIG || d.vol_vec) fast = 0;
+        out[s] = d;
     }
-    out[s] = d;
+    fast = __syncthreads_and(fast);
+    if (threadIdx.x == 0) head->all_fast = fast;
 }
-
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
 
 struct quad {
     float v[4];
 };
 
-// fetch the 4 source samples this thread needs from one channel
-__device__ __forceinline__ void fetch_contig(const float *__restrict__ p, int nf, quad &q)
+template <bool FULL>
+__device__ __forceinline__ void fetch_contig(gf32 p, int nf, quad &q)
 {
-    if (nf == 4) {
-        const f4u t = *reinterpret_cast<const f4u *>(p);
+    if (FULL) {
+        const f4u t = *reinterpret_cast<gf4u>(p);
         q.v[0] = t.x; q.v[1] = t.y; q.v[2] = t.z; q.v[3] = t.w;
     } else {
 #pragma unroll
@@ -89,9 +102,10 @@ __device__ __forceinline__ void fetch_contig(const float *__restrict__ p, int nf
 
 // (x+o) % sl % rl with JavaScript remainder semantics (src/mix-buffers.js:22):
 // negative index -> undefined -> NaN, except -0 which names element 0.
-__device__ __forceinline__ void fetch_general(const mix_desc &d, int64_t x0, int nf, quad &q0, quad &q1)
+__device__ __noinline__ void fetch_general(const mix_desc &d, int64_t x0, int nf, quad &q0, quad &q1)
 {
     const float nanv = __builtin_nanf("");
+    gf32 c0 = (gf32)d.ch0, c1 = (gf32)d.ch1;
     int64_t v = 0, i = 0;
     bool have = false;
 #pragma unroll
@@ -99,7 +113,7 @@ __device__ __forceinline__ void fetch_general(const mix_desc &d, int64_t x0, int
         if (f >= nf) { q0.v[f] = q1.v[f] = 0.0f; continue; }
         const int64_t a = x0 + f + d.o;
         if (a < 0) {
-            if (a % d.asl == 0) { q0.v[f] = d.ch0[0]; q1.v[f] = d.ch1[0]; }
+            if (a % d.asl == 0) { q0.v[f] = c0[0]; q1.v[f] = c1[0]; }
             else { q0.v[f] = q1.v[f] = nanv; }
             continue;
         }
@@ -112,80 +126,100 @@ __device__ __forceinline__ void fetch_general(const mix_desc &d, int64_t x0, int
             if (i == d.rl) i = 0;
             if (v == d.asl) { v = 0; i = 0; }
         }
-        q0.v[f] = d.ch0[i];
-        q1.v[f] = d.ch1[i];
+        q0.v[f] = c0[i];
+        q1.v[f] = c1[i];
     }
 }
 
+// one source folded into the thread's 4 frames (f64 multiply, f64 add, f32 store)
 template <int TCH>
-__global__ __launch_bounds__(256) void k_mix(float *__restrict__ t0, float *__restrict__ t1, int64_t tl,
-                                             const mix_desc *__restrict__ descs, int64_t nsrc)
+__device__ __forceinline__ void accumulate(quad &a0, quad &a1, const quad &q0, const quad &q1, int nch, const double *vol)
 {
-    const int64_t x0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (x0 >= tl) return;
-    const int nf = (tl - x0 >= 4) ? 4 : (int)(tl - x0);
-    quad a0, a1;
-    fetch_contig(t0 + x0, nf, a0);
-    if (TCH == 2) fetch_contig(t1 + x0, nf, a1);
-
-    constexpr int U = 4;  // sources fetched ahead of the (sequential) accumulation
-    for (int64_t s0 = 0; s0 < nsrc; s0 += U) {
-        quad q0[U], q1[U];
-        double vv[U][4];
-        int mode[U], nch[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            mode[u] = MIX_SKIP;
-            nch[u] = 0;
-            if (s0 + u < nsrc) {
-                const mix_desc &d = descs[s0 + u];
-                mode[u] = d.mode;
-                nch[u] = d.nch;
-                if (d.mode == MIX_CONTIG) {
-                    fetch_contig(d.ch0 + d.base + x0, nf, q0[u]);
-                    if (d.nch == 2) fetch_contig(d.ch1 + d.base + x0, nf, q1[u]);
-                } else if (d.mode == MIX_GENERAL) {
-                    fetch_general(d, x0, nf, q0[u], q1[u]);
-                } else if (d.mode == MIX_NAN) {
-#pragma unroll
-                    for (int f = 0; f < 4; f++) q0[u].v[f] = q1[u].v[f] = __builtin_nanf("");
-                }
-                if (d.mode != MIX_SKIP) {
-                    if (d.vol_vec) {
-#pragma unroll
-                        for (int f = 0; f < 4; f++) vv[u][f] = f < nf ? d.vol_vec[x0 + f] : 0.0;
-                    } else {
-#pragma unroll
-                        for (int f = 0; f < 4; f++) vv[u][f] = d.vol;
-                    }
-                }
+    for (int f = 0; f < 4; f++) {
+        if (TCH == 2) {
+            if (nch == 2) {  // stereo -> stereo (:22-23, :50-51)
+                a0.v[f] = (float)((double)a0.v[f] + (double)q0.v[f] * vol[f]);
+                a1.v[f] = (float)((double)a1.v[f] + (double)q1.v[f] * vol[f]);
+            } else {         // mono -> stereo (:28-29, :55-56)
+                const double h = ((double)q0.v[f] / 2.0) * vol[f];
+                a0.v[f] = (float)((double)a0.v[f] + h);
+                a1.v[f] = (float)((double)a1.v[f] + h);
             }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (mode[u] == MIX_SKIP) continue;
-#pragma unroll
-            for (int f = 0; f < 4; f++) {
-                const double vol = vv[u][f];
-                if (TCH == 2) {
-                    if (nch[u] == 2) {  // stereo -> stereo (:22-23, :50-51)
-                        a0.v[f] = (float)((double)a0.v[f] + (double)q0[u].v[f] * vol);
-                        a1.v[f] = (float)((double)a1.v[f] + (double)q1[u].v[f] * vol);
-                    } else {            // mono -> stereo (:28-29, :55-56)
-                        const double h = ((double)q0[u].v[f] / 2.0) * vol;
-                        a0.v[f] = (float)((double)a0.v[f] + h);
-                        a1.v[f] = (float)((double)a1.v[f] + h);
-                    }
-                } else {
-                    if (nch[u] == 2)    // stereo -> mono (:36, :62)
-                        a0.v[f] = (float)((double)a0.v[f] + (((double)q0[u].v[f] + (double)q1[u].v[f]) / 2.0) * vol);
-                    else                // mono -> mono (:41, :66)
-                        a0.v[f] = (float)((double)a0.v[f] + (double)q0[u].v[f] * vol);
-                }
-            }
+        } else {
+            if (nch == 2)    // stereo -> mono (:36, :62)
+                a0.v[f] = (float)((double)a0.v[f] + (((double)q0.v[f] + (double)q1.v[f]) / 2.0) * vol[f]);
+            else             // mono -> mono (:41, :66)
+                a0.v[f] = (float)((double)a0.v[f] + (double)q0.v[f] * vol[f]);
         }
     }
-    if (nf == 4) {
+}
+
+// FULL: the thread owns 4 whole frames (every thread but possibly the last one)
+template <int TCH, bool FULL>
+__device__ __forceinline__ void mix_body(float *__restrict__ t0, float *__restrict__ t1, int64_t x0, int nf,
+                                         const mix_head *__restrict__ head, const mix_desc *__restrict__ descs,
+                                         int64_t nsrc)
+{
+    quad a0, a1;
+    fetch_contig<FULL>((gf32)(t0 + x0), nf, a0);
+    if (TCH == 2) fetch_contig<FULL>((gf32)(t1 + x0), nf, a1);
+
+    if (head->all_fast) {
+        // every source: contiguous run, constant gain.  U sources' loads are in
+        // flight while the (inherently sequential) accumulation drains them.
+        constexpr int U = 8;
+        int64_t s0 = 0;
+        for (; s0 + U <= nsrc; s0 += U) {
+            quad q0[U], q1[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const mix_desc &d = descs[s0 + u];
+                fetch_contig<FULL>((gf32)(d.ch0 + d.base + x0), nf, q0[u]);
+                if (d.nch == 2) fetch_contig<FULL>((gf32)(d.ch1 + d.base + x0), nf, q1[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const mix_desc &d = descs[s0 + u];
+                const double vol[4] = {d.vol, d.vol, d.vol, d.vol};
+                accumulate<TCH>(a0, a1, q0[u], q1[u], d.nch, vol);
+            }
+        }
+        for (; s0 < nsrc; s0++) {
+            const mix_desc &d = descs[s0];
+            quad q0, q1;
+            fetch_contig<FULL>((gf32)(d.ch0 + d.base + x0), nf, q0);
+            if (d.nch == 2) fetch_contig<FULL>((gf32)(d.ch1 + d.base + x0), nf, q1);
+            const double vol[4] = {d.vol, d.vol, d.vol, d.vol};
+            accumulate<TCH>(a0, a1, q0, q1, d.nch, vol);
+        }
+    } else {
+        for (int64_t s = 0; s < nsrc; s++) {
+            const mix_desc &d = descs[s];
+            if (d.mode == MIX_SKIP) continue;
+            quad q0, q1;
+            if (d.mode == MIX_CONTIG) {
+                fetch_contig<FULL>((gf32)(d.ch0 + d.base + x0), nf, q0);
+                if (d.nch == 2) fetch_contig<FULL>((gf32)(d.ch1 + d.base + x0), nf, q1);
+            } else if (d.mode == MIX_GENERAL) {
+                fetch_general(d, x0, nf, q0, q1);
+            } else {
+#pragma unroll
+                for (int f = 0; f < 4; f++) q0.v[f] = q1.v[f] = __builtin_nanf("");
+            }
+            double vol[4];
+            if (d.vol_vec) {
+                gf64 vv = (gf64)d.vol_vec;
+#pragma unroll
+                for (int f = 0; f < 4; f++) vol[f] = f < nf ? vv[x0 + f] : 0.0;
+            } else {
+#pragma unroll
+                for (int f = 0; f < 4; f++) vol[f] = d.vol;
+            }
+            accumulate<TCH>(a0, a1, q0, q1, d.nch, vol);
+        }
+    }
+    if (FULL) {
         f4u o;
         o.x = a0.v[0]; o.y = a0.v[1]; o.z = a0.v[2]; o.w = a0.v[3];
         *reinterpret_cast<f4u *>(t0 + x0) = o;
@@ -201,19 +235,31 @@ __global__ __launch_bounds__(256) void k_mix(float *__restrict__ t0, float *__re
     }
 }
 
-size_t mix_desc_bytes() { return sizeof(mix_desc); }
+template <int TCH>
+__global__ __launch_bounds__(256) void k_mix(float *__restrict__ t0, float *__restrict__ t1, int64_t tl,
+                                             const mix_head *__restrict__ head,
+                                             const mix_desc *__restrict__ descs, int64_t nsrc)
+{
+    const int64_t x0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x0 >= tl) return;
+    if (tl - x0 >= 4) mix_body<TCH, true>(t0, t1, x0, 4, head, descs, nsrc);
+    else mix_body<TCH, false>(t0, t1, x0, (int)(tl - x0), head, descs, nsrc);
+}
 
-hipError_t launch_mix(float *t0, float *t1, int tch, int64_t tl, const wp_src *srcs_dev, void *desc_scratch,
+size_t mix_scratch_bytes(int64_t nsrc) { return sizeof(mix_head) + sizeof(mix_desc) * (size_t)nsrc; }
+
+hipError_t launch_mix(float *t0, float *t1, int tch, int64_t tl, const wp_src *srcs_dev, void *scratch,
                       int64_t nsrc, hipStream_t s)
 {
     if (nsrc <= 0 || tl <= 0) return hipSuccess;
-    mix_desc *descs = reinterpret_cast<mix_desc *>(desc_scratch);
-    hipLaunchKernelGGL(k_mix_prep, dim3((unsigned)((nsrc + 255) / 256)), dim3(256), 0, s, srcs_dev, descs, nsrc, tl, tch);
-    if (tch != 1 && tch != 2) return hipGetLastError();  // nothing to do (reference: silently nothing)
+    if (tch != 1 && tch != 2) return hipSuccess;  // the reference does nothing for other target layouts
+    mix_head *head = reinterpret_cast<mix_head *>(scratch);
+    mix_desc *descs = reinterpret_cast<mix_desc *>(head + 1);
+    hipLaunchKernelGGL(k_mix_prep, dim3(1), dim3(256), 0, s, srcs_dev, head, descs, nsrc, tl, tch);
     const int64_t nthreads = (tl + 3) / 4;
     const dim3 grid((unsigned)((nthreads + 255) / 256)), block(256);
-    if (tch == 2) hipLaunchKernelGGL((k_mix<2>), grid, block, 0, s, t0, t1, tl, descs, nsrc);
-    else hipLaunchKernelGGL((k_mix<1>), grid, block, 0, s, t0, t1, tl, descs, nsrc);
+    if (tch == 2) hipLaunchKernelGGL((k_mix<2>), grid, block, 0, s, t0, t1, tl, head, descs, nsrc);
+    else hipLaunchKernelGGL((k_mix<1>), grid, block, 0, s, t0, t1, tl, head, descs, nsrc);
     return hipGetLastError();
 }
 

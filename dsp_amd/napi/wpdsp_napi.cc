@@ -1,0 +1,404 @@
+// wpdsp_napi.cc — thin Node N-API glue over the C ABI in include/wpdsp.h.
+//
+// Plain C N-API (node_api.h, N-API v4+), no node-addon-api.  Context-aware:
+// the module has no global JS state, so it can be loaded in the main thread
+// and in any number of worker_threads (the reference runs one module instance
+// per Web Worker, src/mix-worker-thread.js).  Typed arrays are read in place
+// (byte offsets of subarray views honoured, SharedArrayBuffer backing accepted);
+// results are fresh Float32Arrays with their own ArrayBuffer, like the
+// reference's (lib/convolve.js:575,582).  Errors are thrown with the class the
+// reference throws: RangeError for an over-long input (lib/convolve.js:590),
+// Error for a bad FFT size (:8-9).
+#include <node_api.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/wpdsp.h"
+
+#define NAPI_CALL(env, call)                                          \
+    do {                                                              \
+        if ((call) != napi_ok) {                                      \
+            napi_throw_error((env), NULL, "N-API call failed: " #call); \
+            return NULL;                                              \
+        }                                                             \
+    } while (0)
+
+static napi_value throw_wp(napi_env env, int rc)
+{
+    const char *msg = wp_last_error();
+    if (rc == WP_ERR_RANGE) napi_throw_range_error(env, NULL, msg);
+    else if (rc == WP_ERR_INVALID) napi_throw_type_error(env, NULL, msg);
+    else napi_throw_error(env, NULL, msg);
+    return NULL;
+}
+
+struct F32View {
+    float *data;
+    size_t length;
+};
+
+static bool get_f32(napi_env env, napi_value v, F32View *out)
+{
+    bool is = false;
+    if (napi_is_typedarray(env, v, &is) != napi_ok || !is) return false;
+    napi_typedarray_type type;
+    size_t length = 0, byte_offset = 0;
+    void *data = NULL;
+    napi_value ab;
+    if (napi_get_typedarray_info(env, v, &type, &length, &data, &ab, &byte_offset) != napi_ok) return false;
+    if (type != napi_float32_array) return false;
+    out->data = (float *)data;  // already advanced by byte_offset
+    out->length = length;
+    return true;
+}
+
+static bool get_f64(napi_env env, napi_value v, double **data, size_t *length)
+{
+    bool is = false;
+    if (napi_is_typedarray(env, v, &is) != napi_ok || !is) return false;
+    napi_typedarray_type type;
+    size_t byte_offset = 0;
+    void *d = NULL;
+    napi_value ab;
+    if (napi_get_typedarray_info(env, v, &type, length, &d, &ab, &byte_offset) != napi_ok) return false;
+    if (type != napi_float64_array) return false;
+    *data = (double *)d;
+    return true;
+}
+
+static napi_value new_f32(napi_env env, size_t n, float **data)
+{
+    napi_value ab, ta;
+    void *p = NULL;
+    NAPI_CALL(env, napi_create_arraybuffer(env, n * sizeof(float), &p, &ab));
+    NAPI_CALL(env, napi_create_typedarray(env, napi_float32_array, n, ab, 0, &ta));
+    *data = (float *)p;
+    return ta;
+}
+
+static bool get_i64(napi_env env, napi_value v, int64_t *out)
+{
+    return napi_get_value_int64(env, v, out) == napi_ok;
+}
+
+static napi_value num(napi_env env, double d)
+{
+    napi_value v;
+    napi_create_double(env, d, &v);
+    return v;
+}
+
+// ---- handles: JS objects wrapping a native pointer, freed by the GC ----------
+static void ir_finalize(napi_env, void *p, void *) { wp_ir_destroy((wp_ir *)p); }
+static void reverb_finalize(napi_env, void *p, void *) { wp_reverb_destroy((wp_reverb *)p); }
+
+static napi_value wrap_ptr(napi_env env, void *p, napi_finalize fin)
+{
+    napi_value obj;
+    NAPI_CALL(env, napi_create_object(env, &obj));
+    NAPI_CALL(env, napi_wrap(env, obj, p, fin, NULL, NULL));
+    return obj;
+}
+
+template <class T>
+static T *unwrap(napi_env env, napi_value v)
+{
+    void *p = NULL;
+    if (napi_unwrap(env, v, &p) != napi_ok || !p) {
+        napi_throw_type_error(env, NULL, "expected a wpdsp handle");
+        return NULL;
+    }
+    return (T *)p;
+}
+
+#define ARGS(n)                                                          \
+    size_t argc = (n);                                                   \
+    napi_value argv[(n)];                                                \
+    NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL)); \
+    if (argc < (n)) {                                                    \
+        napi_throw_type_error(env, NULL, "too few arguments");           \
+        return NULL;                                                     \
+    }
+
+// init() -> number of GPUs
+static napi_value js_init(napi_env env, napi_callback_info)
+{
+    const int n = wp_init();
+    if (n < 0) return throw_wp(env, n);
+    return num(env, n);
+}
+
+// fftLength(L, M) -> N   (lib/convolve.js:554-555)
+static napi_value js_fft_length(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    int64_t L, M;
+    if (!get_i64(env, argv[0], &L) || !get_i64(env, argv[1], &M)) return throw_wp(env, WP_ERR_INVALID);
+    const int32_t n = wp_fft_length(L, M);
+    if (n < 0) {
+        napi_throw_error(env, NULL, "FFT size must be a power of two and bigger than 1");
+        return NULL;
+    }
+    return num(env, n);
+}
+
+// irCreate([Float32Array, ...], L) -> handle   (lib/convolve.js:553-562)
+static napi_value js_ir_create(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    uint32_t nch = 0;
+    NAPI_CALL(env, napi_get_array_length(env, argv[0], &nch));
+    int64_t L;
+    if (!get_i64(env, argv[1], &L) || nch < 1) return throw_wp(env, WP_ERR_INVALID);
+    std::vector<const float *> ptrs(nch);
+    size_t M = 0;
+    for (uint32_t c = 0; c < nch; c++) {
+        napi_value e;
+        NAPI_CALL(env, napi_get_element(env, argv[0], c, &e));
+        F32View v;
+        if (!get_f32(env, e, &v) || (c > 0 && v.length != M)) {
+            napi_throw_type_error(env, NULL, "IR channels must be Float32Arrays of equal length");
+            return NULL;
+        }
+        M = v.length;
+        ptrs[c] = v.data;
+    }
+    wp_ir *ir = wp_ir_create(ptrs.data(), (int)nch, (int64_t)M, L);
+    if (!ir) return throw_wp(env, WP_ERR_HIP);
+    return wrap_ptr(env, ir, ir_finalize);
+}
+
+// irInfo(handle, which)
+static napi_value js_ir_info(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    wp_ir *ir = unwrap<wp_ir>(env, argv[0]);
+    if (!ir) return NULL;
+    int64_t which;
+    if (!get_i64(env, argv[1], &which)) return throw_wp(env, WP_ERR_INVALID);
+    return num(env, (double)wp_ir_info(ir, (int)which));
+}
+
+// convolve(ir, ch, input) -> Float32Array(L+M)   (go, lib/convolve.js:570-583)
+static napi_value js_convolve(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    wp_ir *ir = unwrap<wp_ir>(env, argv[0]);
+    if (!ir) return NULL;
+    int64_t ch;
+    F32View in;
+    if (!get_i64(env, argv[1], &ch) || !get_f32(env, argv[2], &in)) {
+        napi_throw_type_error(env, NULL, "convolve(ir, ch, Float32Array)");
+        return NULL;
+    }
+    float *out = NULL;
+    napi_value ta = new_f32(env, (size_t)wp_ir_info(ir, 5), &out);
+    if (!ta) return NULL;
+    const int rc = wp_convolve(ir, (int)ch, in.data, (int64_t)in.length, out);
+    if (rc) return throw_wp(env, rc);
+    return ta;
+}
+
+// reverbCreate(ir, nch, offset) -> handle
+static napi_value js_reverb_create(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    wp_ir *ir = unwrap<wp_ir>(env, argv[0]);
+    if (!ir) return NULL;
+    int64_t nch, offset;
+    if (!get_i64(env, argv[1], &nch) || !get_i64(env, argv[2], &offset) || nch < 1 || nch > 2) return throw_wp(env, WP_ERR_INVALID);
+    const int32_t job_ch[2] = {0, 1};
+    wp_reverb *r = wp_reverb_create(ir, (int)nch, job_ch, offset);
+    if (!r) return throw_wp(env, WP_ERR_HIP);
+    // the reverb borrows the IR: keep the IR object alive as a property of the handle
+    napi_value obj = wrap_ptr(env, r, reverb_finalize);
+    if (obj) napi_set_named_property(env, obj, "ir", argv[0]);
+    return obj;
+}
+
+static bool collect_channels(napi_env env, napi_value arr, std::vector<F32View> *out)
+{
+    uint32_t n = 0;
+    if (napi_get_array_length(env, arr, &n) != napi_ok) return false;
+    out->resize(n);
+    for (uint32_t c = 0; c < n; c++) {
+        napi_value e;
+        if (napi_get_element(env, arr, c, &e) != napi_ok || !get_f32(env, e, &(*out)[c])) return false;
+    }
+    return true;
+}
+
+// reverbBlock(handle, [Float32Array per channel]) ->
+//   { curr: [Float32Array(L+M)...], retOff, retLen, prevOff, prevLen }
+static napi_value js_reverb_block(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    wp_reverb *r = unwrap<wp_reverb>(env, argv[0]);
+    if (!r) return NULL;
+    std::vector<F32View> in;
+    if (!collect_channels(env, argv[1], &in) || in.empty()) {
+        napi_throw_type_error(env, NULL, "reverbBlock(handle, [Float32Array, ...])");
+        return NULL;
+    }
+    napi_value irv;
+    NAPI_CALL(env, napi_get_named_property(env, argv[0], "ir", &irv));
+    wp_ir *ir = unwrap<wp_ir>(env, irv);
+    if (!ir) return NULL;
+    const size_t n = (size_t)wp_ir_info(ir, 5);
+    std::vector<const float *> ip(in.size());
+    std::vector<float *> op(in.size());
+    napi_value curr;
+    NAPI_CALL(env, napi_create_array_with_length(env, in.size(), &curr));
+    for (size_t c = 0; c < in.size(); c++) {
+        if (in[c].length != in[0].length) {
+            napi_throw_type_error(env, NULL, "channels must have equal length");
+            return NULL;
+        }
+        ip[c] = in[c].data;
+        napi_value ta = new_f32(env, n, &op[c]);
+        if (!ta) return NULL;
+        NAPI_CALL(env, napi_set_element(env, curr, (uint32_t)c, ta));
+    }
+    wp_reverb_view v;
+    const int rc = wp_reverb_block(r, ip.data(), (int64_t)in[0].length, op.data(), &v);
+    if (rc) return throw_wp(env, rc);
+    napi_value res;
+    NAPI_CALL(env, napi_create_object(env, &res));
+    napi_set_named_property(env, res, "curr", curr);
+    napi_set_named_property(env, res, "retOff", num(env, (double)v.ret_off));
+    napi_set_named_property(env, res, "retLen", num(env, (double)v.ret_len));
+    napi_set_named_property(env, res, "prevOff", num(env, (double)v.prev_off));
+    napi_set_named_property(env, res, "prevLen", num(env, (double)v.prev_len));
+    return res;
+}
+
+// reverbSetTail(handle, [Float32Array per channel])
+static napi_value js_reverb_set_tail(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    wp_reverb *r = unwrap<wp_reverb>(env, argv[0]);
+    if (!r) return NULL;
+    std::vector<F32View> pv;
+    if (!collect_channels(env, argv[1], &pv) || pv.empty()) {
+        napi_throw_type_error(env, NULL, "reverbSetTail(handle, [Float32Array, ...])");
+        return NULL;
+    }
+    std::vector<const float *> pp(pv.size());
+    for (size_t c = 0; c < pv.size(); c++) pp[c] = pv[c].data;
+    const int rc = wp_reverb_set_tail(r, pp.data(), (int64_t)pv[0].length);
+    if (rc) return throw_wp(env, rc);
+    return NULL;
+}
+
+// mix(target: [Float32Array...], sources: [{ch:[Float32Array...], rl, sl, vol, volVec?, o}])
+static napi_value js_mix(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    std::vector<F32View> tgt;
+    if (!collect_channels(env, argv[0], &tgt) || tgt.empty()) {
+        napi_throw_type_error(env, NULL, "mix: target must be an array of Float32Arrays");
+        return NULL;
+    }
+    uint32_t nsrc = 0;
+    NAPI_CALL(env, napi_get_array_length(env, argv[1], &nsrc));
+    std::vector<wp_src> srcs(nsrc);
+    for (uint32_t i = 0; i < nsrc; i++) {
+        napi_value s, v;
+        NAPI_CALL(env, napi_get_element(env, argv[1], i, &s));
+        wp_src &d = srcs[i];
+        memset(&d, 0, sizeof(d));
+        NAPI_CALL(env, napi_get_named_property(env, s, "ch", &v));
+        std::vector<F32View> ch;
+        if (!collect_channels(env, v, &ch)) {
+            napi_throw_type_error(env, NULL, "mix: source channels must be Float32Arrays");
+            return NULL;
+        }
+        d.nch = (int32_t)ch.size();
+        for (size_t c = 0; c < ch.size() && c < 2; c++) d.ch[c] = ch[c].data;
+        int64_t t;
+        double f;
+        NAPI_CALL(env, napi_get_named_property(env, s, "rl", &v));
+        if (!get_i64(env, v, &t)) return throw_wp(env, WP_ERR_INVALID);
+        d.rl = t;
+        NAPI_CALL(env, napi_get_named_property(env, s, "sl", &v));
+        if (!get_i64(env, v, &t)) return throw_wp(env, WP_ERR_INVALID);
+        d.sl = t;
+        NAPI_CALL(env, napi_get_named_property(env, s, "o", &v));
+        if (!get_i64(env, v, &t)) return throw_wp(env, WP_ERR_INVALID);
+        d.o = t;
+        NAPI_CALL(env, napi_get_named_property(env, s, "vol", &v));
+        if (napi_get_value_double(env, v, &f) != napi_ok) return throw_wp(env, WP_ERR_INVALID);
+        d.vol = f;
+        bool has = false;
+        NAPI_CALL(env, napi_has_named_property(env, s, "volVec", &has));
+        if (has) {
+            NAPI_CALL(env, napi_get_named_property(env, s, "volVec", &v));
+            napi_valuetype vt;
+            NAPI_CALL(env, napi_typeof(env, v, &vt));
+            if (vt != napi_undefined && vt != napi_null) {
+                double *vec = NULL;
+                size_t vl = 0;
+                if (!get_f64(env, v, &vec, &vl) || vl < tgt[0].length) {
+                    napi_throw_type_error(env, NULL, "mix: volVec must be a Float64Array of the target length");
+                    return NULL;
+                }
+                d.vol_vec = vec;
+            }
+        }
+    }
+    std::vector<float *> tp(tgt.size());
+    for (size_t c = 0; c < tgt.size(); c++) tp[c] = tgt[c].data;
+    const int rc = wp_mix(tp.data(), (int)tgt.size(), (int64_t)tgt[0].length, srcs.data(), (int64_t)nsrc);
+    if (rc) return throw_wp(env, rc);
+    return argv[0];
+}
+
+// mixSl(rl, length) -> (rl*length)|0
+static napi_value js_mix_sl(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    int64_t rl;
+    double len;
+    if (!get_i64(env, argv[0], &rl) || napi_get_value_double(env, argv[1], &len) != napi_ok) return throw_wp(env, WP_ERR_INVALID);
+    return num(env, wp_mix_sl(rl, len));
+}
+
+static napi_value js_ring_pos(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    int64_t a, b, c;
+    if (!get_i64(env, argv[0], &a) || !get_i64(env, argv[1], &b) || !get_i64(env, argv[2], &c)) return throw_wp(env, WP_ERR_INVALID);
+    return num(env, (double)wp_ring_pos(a, b, c));
+}
+
+static napi_value js_beat_rate(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    double sr, bpm;
+    if (napi_get_value_double(env, argv[0], &sr) != napi_ok || napi_get_value_double(env, argv[1], &bpm) != napi_ok)
+        return throw_wp(env, WP_ERR_INVALID);
+    return num(env, (double)wp_beat_rate(sr, bpm));
+}
+
+NAPI_MODULE_INIT()
+{
+    const napi_property_descriptor props[] = {
+        {"init", NULL, js_init, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"fftLength", NULL, js_fft_length, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"irCreate", NULL, js_ir_create, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"irInfo", NULL, js_ir_info, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"convolve", NULL, js_convolve, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"reverbCreate", NULL, js_reverb_create, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"reverbBlock", NULL, js_reverb_block, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"reverbSetTail", NULL, js_reverb_set_tail, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"mix", NULL, js_mix, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"mixSl", NULL, js_mix_sl, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"ringPos", NULL, js_ring_pos, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"beatRate", NULL, js_beat_rate, NULL, NULL, NULL, napi_enumerable, NULL},
+    };
+    if (napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props) != napi_ok) return NULL;
+    return exports;
+}

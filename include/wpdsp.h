@@ -85,6 +85,15 @@ int wp_conv_run_dev(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t 
                     void *stream);
 /* Device bytes of workspace a wp_conv holds. */
 int64_t wp_conv_workspace_bytes(const wp_conv *c);
+/* Measurement hook (no reference counterpart): when enabled, wp_conv_run_dev
+ * brackets each of its three kernels (forward FFT, spectral MAC, inverse FFT)
+ * with HIP events on the caller's stream; wp_conv_profile_read waits for the
+ * last run and returns the three durations in milliseconds. */
+int wp_conv_profile(wp_conv *c, int enable);
+int wp_conv_profile_read(wp_conv *c, float *ms3);
+/* Geometry of a plan: which = 0 jobs, 1 output blocks T, 2 partition size B,
+ * 3 partitions P (padded), 4 blocks per MAC time chunk. */
+int64_t wp_conv_info(const wp_conv *c, int which);
 
 /* ---- block reverb: lib/impulse-reverb.js:10-21, impulse-reverb-stereo.js:11-30 */
 /* Index bookkeeping of one reverb block, in samples relative to the start of

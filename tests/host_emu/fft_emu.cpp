@@ -77,47 +77,58 @@ double test_fft()
     return maxerr / maxmag;
 }
 
+// Odd-frequency transform of a real 2B segment: pack, pre-twist, three stages,
+// bin_split -> compare with the float64 definition; then bin_unsplit, inverse
+// stages, post-twist -> must give back 4*B times the packed samples.
 template <int B>
-double test_split()
+double test_odft()
 {
-    // 2B reals -> packed Z (double DFT) -> split_pair / split_q0 vs the true 2B-point DFT,
-    // then unsplit back to 2*Z.
+    Tables<B> T;
+    constexpr int PT = FftPlan<B>::PT, NT = B / PT;
+    std::vector<c32> thalf(256), wbin(B);
+    for (int j = 0; j < 256; j++) thalf[j] = {(float)cos(M_PI * j / B), (float)-sin(M_PI * j / B)};
+    for (int k = 0; k < B; k++) wbin[k] = {(float)cos(M_PI * (k + 0.5) / B), (float)-sin(M_PI * (k + 0.5) / B)};
     std::vector<double> r(2 * B);
-    srand(7 * B);
-    for (auto &v : r) v = rand() / (double)RAND_MAX - 0.5;
-    const int bins[] = {0, 1, 2, 3, B / 4, B / 2 - 1};
-    double maxerr = 0;
-    auto Zat = [&](int k) {
-        cd acc = 0;
-        for (int n = 0; n < B; n++) acc += cd(r[2 * n], r[2 * n + 1]) * std::polar(1.0, -2 * M_PI * (double)((long long)n * k % B) / B);
-        return acc;
-    };
-    auto Rat = [&](int k) {
-        cd acc = 0;
-        for (int n = 0; n < 2 * B; n++) acc += r[n] * std::polar(1.0, -2 * M_PI * (double)((long long)n * k % (2 * B)) / (2 * B));
-        return acc;
-    };
-    for (int q : bins) {
-        c32 rk, rm, zk2, zm2;
-        if (q == 0) {
-            const cd z0 = Zat(0), zh = Zat(B / 2);
-            split_q0({(float)z0.real(), (float)z0.imag()}, {(float)zh.real(), (float)zh.imag()}, rk, rm);
-            const cd R0 = Rat(0), RB = Rat(B), RH = Rat(B / 2);
-            maxerr = fmax(maxerr, fabs(rk.x - 2 * R0.real()) + fabs(rk.y - 2 * RB.real()));
-            maxerr = fmax(maxerr, std::abs(cd(rm.x, rm.y) - 2.0 * RH));
-            unsplit_q0(rk, rm, zk2, zm2);  // unsplit(2R) = 4Z
-            maxerr = fmax(maxerr, std::abs(cd(zk2.x, zk2.y) - 4.0 * z0) + std::abs(cd(zm2.x, zm2.y) - 4.0 * zh));
-        } else {
-            const cd zk = Zat(q), zm = Zat(B - q);
-            const c32 w = {(float)cos(M_PI * q / B), (float)-sin(M_PI * q / B)};
-            split_pair({(float)zk.real(), (float)zk.imag()}, {(float)zm.real(), (float)zm.imag()}, w, rk, rm);
-            maxerr = fmax(maxerr, std::abs(cd(rk.x, rk.y) - 2.0 * Rat(q)));
-            maxerr = fmax(maxerr, std::abs(cd(rm.x, rm.y) - 2.0 * Rat(B - q)));
-            unsplit_pair(rk, rm, w, zk2, zm2);
-            maxerr = fmax(maxerr, std::abs(cd(zk2.x, zk2.y) - 4.0 * zk) + std::abs(cd(zm2.x, zm2.y) - 4.0 * zm));
-        }
+    srand(11 * B);
+    for (auto &v : r) v = (float)(rand() / (double)RAND_MAX - 0.5);
+    std::vector<c32> a(lds_points<B>()), b(lds_points<B>()), regs(NT * PT);
+    // forward
+    for (int tid = 0; tid < NT; tid++) {
+        c32 *v = &regs[tid * PT];
+        stage_load<B, 0>(tid, v, [&](int n) { return c32{(float)r[2 * n], (float)r[2 * n + 1]}; });
+        pre_twist<B>(tid, v, thalf.data());
+        stage_compute<B, 0, false>(tid, v, T.tw);
+        stage_store<B, 0, false>(tid, v, [&](int i, c32 val, int) { a[lds_pad(i)] = val; });
     }
-    return maxerr / sqrt((double)B);
+    run_stage<B, 1, false>(regs, a, b, T.tw);
+    run_stage<B, 2, false>(regs, b, a, T.tw);
+    std::vector<c32> R2(B);
+    for (int k = 0; k < B; k++) R2[k] = bin_split(a[lds_pad(k)], a[lds_pad(B - 1 - k)], wbin[k]);
+    double maxerr = 0;
+    const int step = B > 1024 ? 37 : 5;
+    for (int k = 0; k < B; k += step) {
+        cd acc = 0;
+        for (int n = 0; n < 2 * B; n++) acc += r[n] * std::polar(1.0, -2 * M_PI * fmod(n * (k + 0.5), 2.0 * B) / (2.0 * B));
+        maxerr = fmax(maxerr, std::abs(cd(R2[k].x, R2[k].y) - 2.0 * acc) / sqrt((double)B));
+    }
+    // inverse: Y = R2 -> Z' -> stages -> post-twist
+    for (int k = 0; k < B; k++) b[lds_pad(k)] = bin_unsplit(R2[k], R2[B - 1 - k], wbin[k]);
+    run_stage<B, 0, true>(regs, b, a, T.tw);
+    run_stage<B, 1, true>(regs, a, b, T.tw);
+    constexpr int R = FftPlan<B>::radix(2);
+    std::vector<c32> out(B);
+    for (int tid = 0; tid < NT; tid++) stage_load<B, 2>(tid, &regs[tid * PT], [&](int i) { return b[lds_pad(i)]; });
+    for (int tid = 0; tid < NT; tid++) {
+        stage_compute<B, 2, true>(tid, &regs[tid * PT], T.tw);
+        stage_store<B, 2, true>(tid, &regs[tid * PT], [&](int i, c32 val, auto tt) {
+            out[i] = post_twist<B, int(tt)>(val, thalf[i & (B / R - 1)]);
+        });
+    }
+    for (int m = 0; m < B; m++) {
+        const cd want = 4.0 * B * cd(r[2 * m], r[2 * m + 1]);
+        maxerr = fmax(maxerr, std::abs(cd(out[m].x, out[m].y) - want) / (4.0 * B));
+    }
+    return maxerr;
 }
 
 int main()
@@ -135,9 +146,8 @@ int main()
     CHECK("fft 2048 inv", (test_fft<2048, true>()), 2e-6);
     CHECK("fft 4096 fwd", (test_fft<4096, false>()), 2e-6);
     CHECK("fft 4096 inv", (test_fft<4096, true>()), 2e-6);
-    CHECK("fft 8192 fwd", (test_fft<8192, false>()), 2e-6);
-    CHECK("fft 8192 inv", (test_fft<8192, true>()), 2e-6);
-    CHECK("split/unsplit 1024", test_split<1024>(), 1e-5);
-    CHECK("split/unsplit 4096", test_split<4096>(), 1e-5);
+    CHECK("odd-frequency rt 1024", test_odft<1024>(), 2e-6);
+    CHECK("odd-frequency rt 2048", test_odft<2048>(), 2e-6);
+    CHECK("odd-frequency rt 4096", test_odft<4096>(), 2e-6);
     return bad;
 }
