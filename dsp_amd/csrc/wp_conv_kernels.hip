@@ -167,7 +167,7 @@ __global__ void k_hpack(const c32 *__restrict__ Zir, c32 *__restrict__ Hc, const
 
 // loads in flight per lane in k_mac (must divide PG so ring slots stay static)
 #ifndef WP_MAC_DEPTH
-#define WP_MAC_DEPTH(PG) ((PG) <= 12 ? (PG) : 8)
+#define WP_MAC_DEPTH(PG) ((PG) <= 12 ? (PG) : ((PG) == 24 ? 12 : 8))
 #endif
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,112 @@
+"""CPU-side checks of the drop-in boundary (no GPU, no compute calls):
+the C-ABI library loads and exports every symbol include/wpdsp.h declares, the
+integer helpers match the golden vectors, the product path fails loudly without
+a GPU, the FFT stage code passes its host emulation, the Node addon + shims load."""
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "wpdsp.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dsp_amd import capi
+    lib = capi.lib()
+    declared = _header_functions()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), "libwpdsp.so lacks %s" % name
+    # and the Python binding covers the same set
+    assert sorted(capi.PROTOTYPES) == declared
+    assert C.sizeof(capi.WpSrc) == 64 and C.sizeof(capi.WpReverbView) == 40
+
+
+def test_integer_helpers_match_reference_vectors():
+    from dsp_amd import capi
+    lib = capi.lib()
+    g2 = load_golden("g2_tables.json")
+    for n, N in g2["next_pot_via_kernel_len"]:
+        assert lib.wp_next_pot(n) == N
+    assert lib.wp_next_pot(0) == 1
+    assert lib.wp_fft_length(44100, 22050) == 131072
+    assert lib.wp_fft_length(2880000, 96000) == 4194304
+    assert lib.wp_fft_length(1 << 30, 1) == capi.WP_ERR_FFT_SIZE
+    g6 = load_golden("g6_ring_and_loop.json")
+    for b in g6["beat"]:
+        assert lib.wp_beat_rate(b["sr"], b["bpm"]) == b["beat_rate"]
+    # ring buffer replay (test/ring-buffer.js:14-39)
+    buf, needle = [0.0] * 3, 0
+    for st in g6["ring3"]:
+        buf[needle] = st["write"]
+        needle = lib.wp_ring_advance(needle, 3)
+        assert buf == st["buffer"]
+        for k, v in st["reads"].items():
+            assert buf[lib.wp_ring_pos(needle, int(k), 3)] == v
+    # (rl*length)|0
+    assert lib.wp_mix_sl(8, 0.75) == 6 and lib.wp_mix_sl(6, 2.5) == 15
+    assert lib.wp_mix_sl(8, float("nan")) == 0 and lib.wp_mix_sl(1 << 31, 1.0) == -(1 << 31)
+
+
+def test_reverb_view_arithmetic_matches_reference_blocks():
+    """Index work is bit-exact: the subarray() shapes of every golden reverb block."""
+    from dsp_amd import capi
+    lib = capi.lib()
+    g = load_golden("g3_reverb_blocks.json")
+    n = 0
+    for run in g["runs"]:
+        M = len(run["ir"][0]) if run["params"].get("length", -1) < 0 else min(len(run["ir"][0]), run["params"]["length"])
+        off = run["params"].get("offset", 0)
+        for blk in run["blocks"]:
+            v = capi.WpReverbView()
+            assert lib.wp_reverb_view_for(run["L"], M, off, run["L"], C.byref(v)) == 0
+            assert v.curr_len * 4 == blk["ret"][0]["buffer_bytes"]
+            assert v.ret_len == blk["ret"][0]["length"] and v.ret_off * 4 == blk["ret"][0]["byte_offset"]
+            assert v.prev_len == blk["prev"][0]["length"] and v.prev_off * 4 == blk["prev"][0]["byte_offset"]
+            n += 1
+    assert n > 40
+
+
+def test_no_cpu_fallback_without_gpu():
+    from dsp_amd import capi, convolve, mix
+    if capi.lib().wp_init() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="HIP device"):
+        convolve.fft_process_kernel(8, np.ones(3, np.float32))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        mix.mix_buffers([np.zeros(4, np.float32)], [np.ones(4, np.float32)])
+
+
+def test_synthetic_ir_matches_oracle_generator(oracle):
+    from dsp_amd import device
+    for M, seed in [(5, 21), (300, 16), (22050, 500000)]:
+        assert np.array_equal(device.synth_ir(M, seed).view(np.uint32), oracle.synth_ir(M, seed).view(np.uint32))
+
+
+def test_fft_stage_code_host_emulation(tmp_path):
+    exe = str(tmp_path / "fft_emu")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "host_emu", "fft_emu.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "FAIL" not in out.stdout
+
+
+def test_node_addon_and_shims_load():
+    node = shutil.which("node")
+    addon = os.path.join(ROOT, "dsp_amd", "napi", "wpdsp.node")
+    if not node or not os.path.exists(addon):
+        pytest.skip("node or the built addon is not available")
+    out = subprocess.run([node, "--no-warnings", os.path.join(ROOT, "tests", "node", "test_load.mjs")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("ok load")
