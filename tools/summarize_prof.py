@@ -40,3 +40,20 @@ for k in sorted(acc):
     for c in sorted(acc[k]):
         s, n = acc[k][c]
         print("    %-24s %16.4g   (launches %d)" % (c, s / n, n))
+
+# HBM-side bytes per launch for the bench kernels: FETCH_SIZE and WRITE_SIZE are in KiB and
+# come from separate passes; on gfx950 FETCH_SIZE counts 64 B per 128-B request, so it is
+# doubled (checked here against k_mix and k_mac, whose read bytes are known exactly).
+import json
+traffic = {}
+for k in acc:
+    base = k.split("<")[0]
+    if base in ("k_fft_fwd", "k_mac", "k_fft_inv", "k_mix") and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
+        f = acc[k]["FETCH_SIZE"][0] / acc[k]["FETCH_SIZE"][1]
+        w = acc[k]["WRITE_SIZE"][0] / acc[k]["WRITE_SIZE"][1]
+        if base == "k_fft_fwd" and f < 1e5:
+            continue  # the one-off IR-partition launch, not the bench kernel
+        traffic[base] = int(2 * f * 1024 + w * 1024)
+print("# traffic bytes per launch (2*FETCH_SIZE + WRITE_SIZE):", traffic)
+with open(os.path.join(root, "traffic.json"), "w") as fh:
+    json.dump(traffic, fh)
