@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--ir-seconds", type=float, default=2.0)
     ap.add_argument("--rate", type=int, default=48000)
+    ap.add_argument("--unfused", action="store_true",
+                    help="write every track's reverb result and mix it in a second kernel (wp_conv_run_dev + wp_mix_dev) "
+                         "instead of the fused reverb+mix entry point (wp_conv_mix_run_dev)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tracks", type=int, default=4, help="stereo tracks in the bounded CPU sample")
     return ap.parse_args()
@@ -95,29 +98,40 @@ def main():
     t_lo, _ = dev.shard_range(tracks * world, rank, world)
     for j in range(njobs):
         dev.synth_noise(x[j], 1000 + 2 * (t_lo + j // 2) + (j % 2))
-    out = torch.empty((njobs, stride_out), dtype=torch.float32, device="cuda")
     bus = torch.zeros((2, F), dtype=torch.float32, device="cuda")
-    mix = dev.DeviceMix([{"ch": [out[2 * t], out[2 * t + 1]], "rl": F, "sl": F, "vol": 1.0 / 256, "o": 0}
-                         for t in range(tracks)])
+    vol = [1.0 / 256] * tracks
+    fused = not a.unfused
+    if fused:
+        kern_ms = {"k_fft_fwd": 0.0, "k_mac": 0.0, "k_fft_inv_mix": 0.0}
+    else:
+        out = torch.empty((njobs, stride_out), dtype=torch.float32, device="cuda")
+        mix = dev.DeviceMix([{"ch": [out[2 * t], out[2 * t + 1]], "rl": F, "sl": F, "vol": vol[t], "o": 0}
+                             for t in range(tracks)])
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        kern_ms = {"k_fft_fwd": 0.0, "k_mac": 0.0, "k_fft_inv": 0.0, "k_mix": 0.0}
     conv.profile(True)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    kern_ms = {"k_fft_fwd": 0.0, "k_mac": 0.0, "k_fft_inv": 0.0, "k_mix": 0.0}
 
     def step(timed):
-        conv.run(x, out)
         bus.zero_()
-        ev[0].record()
-        mix.run([bus[0], bus[1]])
-        ev[1].record()
+        if fused:
+            conv.run_mix(x, [bus[0], bus[1]], vol)
+        else:
+            conv.run(x, out)
+            ev[0].record()
+            mix.run([bus[0], bus[1]])
+            ev[1].record()
         if world > 1:
             dev.reduce_master_bus(bus, dist, dst=0)
         if timed:
             f, m, i = conv.profile_read()
-            ev[1].synchronize()
             kern_ms["k_fft_fwd"] += f
             kern_ms["k_mac"] += m
-            kern_ms["k_fft_inv"] += i
-            kern_ms["k_mix"] += ev[0].elapsed_time(ev[1])
+            if fused:
+                kern_ms["k_fft_inv_mix"] += i
+            else:
+                ev[1].synchronize()
+                kern_ms["k_fft_inv"] += i
+                kern_ms["k_mix"] += ev[0].elapsed_time(ev[1])
 
     for _ in range(a.warmup):
         step(False)
@@ -143,12 +157,15 @@ def main():
         total_samples = world * njobs * out_len * K
         B = capi_info(conv, 2)
         T = capi_info(conv, 1)
-        Tin = min(T, (F + B - 1) // B + 1)
+        # blocks each kernel touches: the fused path only needs the blocks that reach the bus (tl = F)
+        Tout = (F + B - 1) // B if fused else T
+        Tin = min(Tout, (F + B - 1) // B + 1)
         # algorithmic bytes per launch (see DESIGN.md "Kernels and rooflines")
         alg = {
             "k_fft_fwd": njobs * (4 * F + 8 * B * Tin),
-            "k_mac": njobs * (8 * B * Tin + 8 * B * T),
+            "k_mac": njobs * (8 * B * Tin + 8 * B * Tout),
             "k_fft_inv": njobs * (8 * B * T + 4 * out_len),
+            "k_fft_inv_mix": njobs * 8 * B * Tout + 2 * 2 * 4 * F,
             "k_mix": F * (4 * 2 * tracks + 2 * 4 * 2),
         }
         avg = {k: v / K for k, v in kern_ms.items()}
@@ -169,6 +186,7 @@ def main():
             "config": {"workload": "batched reverb+mix: %d stereo tracks/GPU x %.0f s @ %d Hz x %.0f s stereo IR, "
                                    "one go() per channel-job then mixBuffers into a stereo bus" % (tracks, a.seconds, a.rate, a.ir_seconds),
                        "tracks_per_gpu": tracks, "frames": F, "ir_len": M, "partition": B, "blocks": T,
+                       "path": "fused reverb+mix (wp_conv_mix_run_dev)" if fused else "wp_conv_run_dev + wp_mix_dev",
                        "parallelism": "tracks sharded over %d GPU(s), RCCL reduce of the bus" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

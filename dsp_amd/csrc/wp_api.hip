@@ -228,6 +228,7 @@ struct wp_conv {
     bool prof;
     bool prof_valid;
     hipEvent_t ev[4];
+    double *vol_dev;    // per-source gains of the fused reverb+mix call
 };
 
 struct wp_reverb {
@@ -415,6 +416,7 @@ extern "C" wp_conv *wp_conv_create(wp_ir *ir, int njobs, const int32_t *job_ch)
     c->Z = c->W = nullptr;
     c->prof = c->prof_valid = false;
     for (auto &e : c->ev) e = nullptr;
+    c->vol_dev = nullptr;
     const size_t sbytes = sizeof(c32) * (size_t)njobs * c->T * ir->B;
     hipError_t e = hipMalloc((void **)&c->job_irch, sizeof(int32_t) * njobs);
     if (e == hipSuccess) e = hipMemcpy(c->job_irch, job_ch, sizeof(int32_t) * njobs, hipMemcpyHostToDevice);
@@ -435,6 +437,7 @@ extern "C" void wp_conv_destroy(wp_conv *c)
     if (c->job_irch) (void)hipFree(c->job_irch);
     if (c->Z) (void)hipFree(c->Z);
     if (c->W) (void)hipFree(c->W);
+    if (c->vol_dev) (void)hipFree(c->vol_dev);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     delete c;
@@ -486,6 +489,26 @@ static int check_in_len(const wp_ir *ir, int64_t in_len)
     return WP_OK;
 }
 
+// forward FFTs + spectral MAC for output blocks [0, Tout); leaves W ready
+static int conv_front(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len, int Tout, hipStream_t s)
+{
+    const wp_ir *ir = c->ir;
+    const int B = ir->B, T = c->T;
+    int Tin = (int)((in_len + B - 1) / B) + 1;
+    if (Tin > Tout) Tin = Tout;  // later input blocks cannot reach the requested outputs
+    if (in_len == 0) Tin = 0;
+    if (c->prof) HIPCHK(hipEventRecord(c->ev[0], s));
+    if (Tin > 0) HIPCHK(launch_fft_fwd(B, false, in_dev, in_stride, in_len, c->Z, T, Tin, c->njobs, ir->tables, s));
+    if (c->prof) HIPCHK(hipEventRecord(c->ev[1], s));
+    if (Tin == 0)  // no input at all: the result is zeros
+        HIPCHK(hipMemsetAsync(c->W, 0, sizeof(c32) * (size_t)c->njobs * T * B, s));
+    else
+        HIPCHK(launch_mac(ir->PG, c->Z, c->W, ir->Hp, ir->tables + table_wsplit_offset(B), c->job_irch, B, T, Tout, Tin,
+                          ir->Pp, c->njobs, c->tchunk, s));
+    if (c->prof) HIPCHK(hipEventRecord(c->ev[2], s));
+    return WP_OK;
+}
+
 extern "C" int wp_conv_run_dev(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len, float *out_dev,
                                int64_t out_stride, const float *prev_dev, int64_t prev_stride, int64_t prev_len,
                                void *stream)
@@ -495,22 +518,35 @@ extern "C" int wp_conv_run_dev(wp_conv *c, const float *in_dev, int64_t in_strid
     const wp_ir *ir = c->ir;
     if (int rc = check_in_len(ir, in_len)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int B = ir->B, T = c->T;
-    int Tin = (int)((in_len + B - 1) / B) + 1;
-    if (Tin > T) Tin = T;
-    if (in_len == 0) Tin = 0;
-    if (c->prof) HIPCHK(hipEventRecord(c->ev[0], s));
-    if (Tin > 0) HIPCHK(launch_fft_fwd(B, false, in_dev, in_stride, in_len, c->Z, T, Tin, c->njobs, ir->tables, s));
-    if (c->prof) HIPCHK(hipEventRecord(c->ev[1], s));
-    if (Tin == 0)  // no input at all: the result is L+M zeros
-        HIPCHK(hipMemsetAsync(c->W, 0, sizeof(c32) * (size_t)c->njobs * T * B, s));
-    else
-        HIPCHK(launch_mac(ir->PG, c->Z, c->W, ir->Hp, ir->tables + table_wsplit_offset(B), c->job_irch, B, T, Tin, ir->Pp,
-                          c->njobs, c->tchunk, s));
-    if (c->prof) HIPCHK(hipEventRecord(c->ev[2], s));
+    if (int rc = conv_front(c, in_dev, in_stride, in_len, c->T, s)) return rc;
     if (prev_dev && prev_len > ir->L + ir->M) prev_len = ir->L + ir->M;
-    HIPCHK(launch_fft_inv(B, c->W, T, c->njobs, out_dev, out_stride, ir->L + ir->M, prev_len > 0 ? prev_dev : nullptr,
-                          prev_stride, prev_len, ir->tables, s));
+    HIPCHK(launch_fft_inv(ir->B, c->W, c->T, c->njobs, out_dev, out_stride, ir->L + ir->M,
+                          prev_len > 0 ? prev_dev : nullptr, prev_stride, prev_len, ir->tables, s));
+    if (c->prof) {
+        HIPCHK(hipEventRecord(c->ev[3], s));
+        c->prof_valid = true;
+    }
+    return WP_OK;
+}
+
+extern "C" int wp_conv_mix_run_dev(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len,
+                                   float *const *tgt_dev, int64_t tl, const double *vol, void *stream)
+{
+    if (int rc = need_device()) return rc;
+    if (!c || !tgt_dev || !tgt_dev[0] || !tgt_dev[1] || !vol || (!in_dev && in_len > 0))
+        return fail(WP_ERR_INVALID, "wp_conv_mix_run_dev: null argument");
+    const wp_ir *ir = c->ir;
+    if (c->njobs % 2) return fail(WP_ERR_INVALID, "wp_conv_mix_run_dev: needs an even number of jobs (stereo sources)");
+    if (tl < 0 || tl > ir->L + ir->M) return fail(WP_ERR_INVALID, "wp_conv_mix_run_dev: target length %lld exceeds the result length %lld", (long long)tl, (long long)(ir->L + ir->M));
+    if (int rc = check_in_len(ir, in_len)) return rc;
+    if (tl == 0) return WP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int nsrc = c->njobs / 2;
+    if (!c->vol_dev) HIPCHK(hipMalloc((void **)&c->vol_dev, sizeof(double) * nsrc));
+    HIPCHK(hipMemcpyAsync(c->vol_dev, vol, sizeof(double) * nsrc, hipMemcpyHostToDevice, s));
+    const int Tout = (int)((tl + ir->B - 1) / ir->B);
+    if (int rc = conv_front(c, in_dev, in_stride, in_len, Tout, s)) return rc;
+    HIPCHK(launch_fft_inv_mix(ir->B, c->W, c->T, Tout, nsrc, tgt_dev[0], tgt_dev[1], tl, c->vol_dev, ir->tables, s));
     if (c->prof) {
         HIPCHK(hipEventRecord(c->ev[3], s));
         c->prof_valid = true;

@@ -35,12 +35,12 @@ template <int B, bool INV>
 __device__ __forceinline__ void middle_stages(int tid, c32 *v, c32 *lds, const TwTables<B> &tw)
 {
     stage_compute<B, 0, INV>(tid, v, tw);
-    stage_store<B, 0, INV>(tid, v, [&](int i, c32 val, int) { lds[lds_pad(i)] = val; });
+    stage_store<B, 0, INV>(tid, v, [&](int i, c32 val, int, int) { lds[lds_pad(i)] = val; });
     __syncthreads();
     stage_load<B, 1>(tid, v, [&](int i) { return lds[lds_pad(i)]; });
     __syncthreads();
     stage_compute<B, 1, INV>(tid, v, tw);
-    stage_store<B, 1, INV>(tid, v, [&](int i, c32 val, int) { lds[lds_pad(i)] = val; });
+    stage_store<B, 1, INV>(tid, v, [&](int i, c32 val, int, int) { lds[lds_pad(i)] = val; });
     __syncthreads();
     stage_load<B, 2>(tid, v, [&](int i) { return lds[lds_pad(i)]; });
     stage_compute<B, 2, INV>(tid, v, tw);
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_fwd(const float *__r
     pre_twist<B>(tid, v, tables + table_thalf_offset(B));
     middle_stages<B, false>(tid, v, lds, tw);
     c32 *z = Z + ((int64_t)job * T + t) * B;
-    stage_store<B, 2, false>(tid, v, [&](int i, c32 val, int) { z[i] = val; });
+    stage_store<B, 2, false>(tid, v, [&](int i, c32 val, int, int) { z[i] = val; });
 }
 
 // ---------------------------------------------------------------------------
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv(const c32 *__res
                       (!pv || prev_len <= o0 || (o0 + B <= prev_len && (reinterpret_cast<uintptr_t>(pv + o0) & 7) == 0));
     const bool addp = pv && o0 + B <= prev_len;
     const c32 *thalf = tables + table_thalf_offset(B);
-    stage_store<B, 2, true>(tid, v, [&](int i, c32 val, auto tt) {
+    stage_store<B, 2, true>(tid, v, [&](int i, c32 val, auto tt, auto) {
         if constexpr (int(tt) >= R / 2) {  // only the second half of the block is output
             val = post_twist<B, int(tt)>(val, thalf[i & (B / R - 1)]);
             const int64_t o = o0 + 2 * (int64_t)(i - B / 2);
@@ -136,6 +136,98 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv(const c32 *__res
                 if (o < out_len) y[o] = val.x + ((pv && o < prev_len) ? pv[o] : 0.0f);
                 if (o + 1 < out_len) y[o + 1] = val.y + ((pv && o + 1 < prev_len) ? pv[o + 1] : 0.0f);
             }
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------
+// Fused inverse FFT + master-bus mix.  Equivalent to k_fft_inv for every job
+// followed by mixBuffers(bus, [[y_0,y_1],1,vol_0,0], [[y_2,y_3],1,vol_1,0], ...)
+// (src/mix-buffers.js:49-52, stereo source -> stereo target), without ever
+// writing the per-track results: one workgroup owns output block t of one bus channel,
+// walks the jobs IN SOURCE ORDER, inverse-transforms W[job][t] and folds the
+// samples into register-resident bus accumulators with the reference's
+// arithmetic (f64 multiply, f64 add, f32 round per source), so the bus is
+// bit-identical to mixing the unfused outputs.  The next job's spectrum is
+// loaded while the current one is transformed.
+__device__ __forceinline__ float mix_fold(float acc, float y, double vol)
+{
+    return (float)((double)acc + (double)y * vol);  // this file is built with -ffp-contract=off
+}
+
+template <int B>
+__global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv_mix(const c32 *__restrict__ W, int T, int nsrc,
+                                                                   float *__restrict__ bus0, float *__restrict__ bus1,
+                                                                   int64_t tl, const double *__restrict__ vol,
+                                                                   const c32 *__restrict__ tables)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    c32 *lds = reinterpret_cast<c32 *>(smem);
+    c32 *tws = lds + lds_points<B>();
+    constexpr int PT = FftPlan<B>::PT, R = FftPlan<B>::radix(2), NT = B / PT, NS = B / R;
+    constexpr int NO = PT / 2;  // complex outputs per thread that belong to the block's second half
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x;
+    const int ch = blockIdx.y;  // the two bus channels are independent sums: one workgroup each
+    float *__restrict__ bus = ch ? bus1 : bus0;
+    const TwTables<B> tw = load_tables<B>(tables, tws, tid);
+    const c32 *thalf = tables + table_thalf_offset(B);
+    const int64_t o0 = (int64_t)t * B;
+    const bool full = (o0 + B <= tl) && ((reinterpret_cast<uintptr_t>(bus + o0) & 7) == 0);
+
+    // bus accumulators: sample pair `slot` of this thread sits at o0 + 2*(i - B/2), i = j + tt*NS
+    c32 acc[NO];
+    auto each_out = [&](auto &&f) {  // f(slot, sample offset) for every kept output of this thread
+        static_for<0, PT / R>([&](auto u) {
+            static_for<R / 2, R>([&](auto tt) {
+                const int i = tid + int(u) * NT + int(tt) * NS;
+                f(ic<int(u) * (R / 2) + int(tt) - R / 2>{}, o0 + 2 * (int64_t)(i - B / 2));
+            });
+        });
+    };
+    each_out([&](auto slot, int64_t o) {
+        if (full) {
+            acc[slot] = *reinterpret_cast<const c32 *>(bus + o);
+        } else {
+            acc[slot].x = o < tl ? bus[o] : 0.f;
+            acc[slot].y = o + 1 < tl ? bus[o + 1] : 0.f;
+        }
+    });
+
+    auto fetch = [&](int src, c32 *v) {  // source index clamped: always a valid row
+        const c32 *w = W + ((int64_t)(2 * (src < nsrc ? src : nsrc - 1) + ch) * T + t) * B;
+        stage_load<B, 0>(tid, v, [&](int n) { return w[n]; });
+    };
+    auto transform_fold = [&](c32 *v, double g) {
+        middle_stages<B, true>(tid, v, lds, tw);
+        stage_store<B, 2, true>(tid, v, [&](int i, c32 val, auto tt, auto u) {
+            if constexpr (int(tt) >= R / 2) {
+                val = post_twist<B, int(tt)>(val, thalf[i & (NS - 1)]);
+                constexpr int slot = int(u) * (R / 2) + int(tt) - R / 2;
+                acc[slot].x = mix_fold(acc[slot].x, val.x, g);
+                acc[slot].y = mix_fold(acc[slot].y, val.y, g);
+            }
+        });
+        __syncthreads();  // every lane is done reading LDS before the next transform overwrites it
+    };
+
+    // two register sets: the next source's spectrum is in flight while this one is transformed
+    c32 v[PT], vn[PT];
+    fetch(0, vn);
+#pragma unroll 1
+    for (int s = 0; s < nsrc; s++) {
+#pragma unroll
+        for (int i = 0; i < PT; i++) v[i] = vn[i];
+        fetch(s + 1, vn);
+        transform_fold(v, vol[s]);
+    }
+
+    each_out([&](auto slot, int64_t o) {
+        if (full) {
+            *reinterpret_cast<c32 *>(bus + o) = acc[slot];
+        } else {
+            if (o < tl) bus[o] = acc[slot].x;
+            if (o + 1 < tl) bus[o + 1] = acc[slot].y;
         }
     });
 }
@@ -186,8 +278,8 @@ __global__ void k_hpack(const c32 *__restrict__ Zir, c32 *__restrict__ Hc, const
 template <int PG, bool ACCUM>
 __global__ __launch_bounds__(256) void k_mac(const c32 *__restrict__ Z, c32 *__restrict__ W,
                                              const c32 *__restrict__ Hc, const c32 *__restrict__ wbin,
-                                             const int32_t *__restrict__ job_irch, int B, int T, int Tin, int Pp,
-                                             int p0, int tchunk)
+                                             const int32_t *__restrict__ job_irch, int B, int T, int Tout, int Tin,
+                                             int Pp, int p0, int tchunk)
 {
     constexpr int D = WP_MAC_DEPTH(PG);
     static_assert(PG % D == 0, "ring");
@@ -195,7 +287,7 @@ __global__ __launch_bounds__(256) void k_mac(const c32 *__restrict__ Z, c32 *__r
     const int k = lane_bin(slot, B);
     const int job = blockIdx.y;
     const int ta = blockIdx.z * tchunk;
-    const int tb = (ta + tchunk < T) ? ta + tchunk : T;
+    const int tb = (ta + tchunk < Tout) ? ta + tchunk : Tout;  // only blocks [0, Tout) are needed
     const c32 w = wbin[k];
     const int irch = job_irch[job];
 
@@ -329,6 +421,30 @@ hipError_t launch_fft_inv(int B, const c32 *W, int T, int njobs, float *out, int
     return hipErrorInvalidValue;
 }
 
+template <int B>
+static hipError_t launch_inv_mix_t(const c32 *W, int T, int nblocks, int nsrc, float *bus0, float *bus1, int64_t tl,
+                                   const double *vol, const c32 *tables, hipStream_t s)
+{
+    if (fft_lds_bytes<B>() > 48 * 1024) {
+        hipError_t e = set_lds_attr<B>((const void *)k_fft_inv_mix<B>);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_fft_inv_mix<B>), dim3(nblocks, 2), dim3(B / FftPlan<B>::PT), fft_lds_bytes<B>(), s, W, T, nsrc,
+                       bus0, bus1, tl, vol, tables);
+    return hipGetLastError();
+}
+
+hipError_t launch_fft_inv_mix(int B, const c32 *W, int T, int nblocks, int nsrc, float *bus0, float *bus1, int64_t tl,
+                              const double *vol, const c32 *tables, hipStream_t s)
+{
+    switch (B) {
+    case 1024: return launch_inv_mix_t<1024>(W, T, nblocks, nsrc, bus0, bus1, tl, vol, tables, s);
+    case 2048: return launch_inv_mix_t<2048>(W, T, nblocks, nsrc, bus0, bus1, tl, vol, tables, s);
+    case 4096: return launch_inv_mix_t<4096>(W, T, nblocks, nsrc, bus0, bus1, tl, vol, tables, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_hpack(const c32 *Zir, c32 *Hc, const c32 *wbin, int B, int P, int Pp, int nch, hipStream_t s)
 {
     const dim3 grid(B / 256, P, nch), block(256);
@@ -338,28 +454,28 @@ hipError_t launch_hpack(const c32 *Zir, c32 *Hc, const c32 *wbin, int B, int P, 
 
 template <int PG>
 static hipError_t launch_mac_t(const c32 *Z, c32 *W, const c32 *Hp, const c32 *wsplit, const int32_t *job_irch,
-                               int B, int T, int Tin, int Pp, int njobs, int tchunk, hipStream_t s)
+                               int B, int T, int Tout, int Tin, int Pp, int njobs, int tchunk, hipStream_t s)
 {
-    const int nchunks = (T + tchunk - 1) / tchunk;
+    const int nchunks = (Tout + tchunk - 1) / tchunk;
     const dim3 grid(B / 256, njobs, nchunks), block(256);
     for (int p0 = 0; p0 < Pp; p0 += PG) {
         if (p0 == 0)
-            hipLaunchKernelGGL((k_mac<PG, false>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tin, Pp, p0, tchunk);
+            hipLaunchKernelGGL((k_mac<PG, false>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, p0, tchunk);
         else
-            hipLaunchKernelGGL((k_mac<PG, true>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tin, Pp, p0, tchunk);
+            hipLaunchKernelGGL((k_mac<PG, true>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, p0, tchunk);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_mac(int PG, const c32 *Z, c32 *W, const c32 *Hp, const c32 *wsplit, const int32_t *job_irch,
-                      int B, int T, int Tin, int Pp, int njobs, int tchunk, hipStream_t s)
+                      int B, int T, int Tout, int Tin, int Pp, int njobs, int tchunk, hipStream_t s)
 {
     switch (PG) {
-    case 4: return launch_mac_t<4>(Z, W, Hp, wsplit, job_irch, B, T, Tin, Pp, njobs, tchunk, s);
-    case 8: return launch_mac_t<8>(Z, W, Hp, wsplit, job_irch, B, T, Tin, Pp, njobs, tchunk, s);
-    case 12: return launch_mac_t<12>(Z, W, Hp, wsplit, job_irch, B, T, Tin, Pp, njobs, tchunk, s);
-    case 16: return launch_mac_t<16>(Z, W, Hp, wsplit, job_irch, B, T, Tin, Pp, njobs, tchunk, s);
-    case 24: return launch_mac_t<24>(Z, W, Hp, wsplit, job_irch, B, T, Tin, Pp, njobs, tchunk, s);
+    case 4: return launch_mac_t<4>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, tchunk, s);
+    case 8: return launch_mac_t<8>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, tchunk, s);
+    case 12: return launch_mac_t<12>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, tchunk, s);
+    case 16: return launch_mac_t<16>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, tchunk, s);
+    case 24: return launch_mac_t<24>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, tchunk, s);
     }
     return hipErrorInvalidValue;
 }

@@ -13,6 +13,7 @@
 //   out    = DFT_R(in)
 //   y[(j - k)*R + k + t*Ns] = out[t]
 #pragma once
+#include <math.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -28,7 +29,11 @@ struct alignas(8) c32 {
 };
 WP_HD c32 operator+(c32 a, c32 b) { return {a.x + b.x, a.y + b.y}; }
 WP_HD c32 operator-(c32 a, c32 b) { return {a.x - b.x, a.y - b.y}; }
-WP_HD c32 cmul(c32 a, c32 b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// Every multiply-add in this file is spelled with fmaf and the kernels are built
+// with -ffp-contract=off, so two kernels that inline the same function compute
+// the same bits (the fused reverb+mix kernel must reproduce the unfused
+// samples exactly) and the host emulation follows the same rounding sequence.
+WP_HD c32 cmul(c32 a, c32 b) { return {fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x)}; }
 WP_HD c32 cconj(c32 a) { return {a.x, -a.y}; }
 
 // compile-time loop: f(integral_constant<int, I>) for I in [0, N)
@@ -73,7 +78,7 @@ WP_HD c32 mul_w32(c32 a)
     } else {
         constexpr float c = w32_cos(i);
         constexpr float s = INV ? w32_sin(i) : -w32_sin(i);
-        return {a.x * c - a.y * s, a.x * s + a.y * c};
+        return {fmaf(a.x, c, -(a.y * s)), fmaf(a.x, s, a.y * c)};
     }
 }
 
@@ -214,7 +219,7 @@ WP_HD void stage_compute(int tid, c32 *v, const TwTables<B> &tw)
         Dft<R, INV>::run(v + u * R);
     });
 }
-// store: dst((j-k)*R + k + t*NS, X[t])
+// store: dst((j-k)*R + k + t*NS, X[t], t, u)  (t, u are compile-time constants)
 template <int B, int S, bool INV, class Dst>
 WP_HD void stage_store(int tid, const c32 *v, Dst &&dst)
 {
@@ -224,7 +229,7 @@ WP_HD void stage_store(int tid, const c32 *v, Dst &&dst)
         const int j = tid + u * NT;
         const int k = j & (NS - 1);
         const int base = (j - k) * R + k;
-        static_for<0, R>([&](auto t) { dst(base + t * NS, v[u * R + Dft<R, INV>::perm(t)], t); });
+        static_for<0, R>([&](auto t) { dst(base + t * NS, v[u * R + Dft<R, INV>::perm(t)], t, u); });
     });
 }
 
@@ -257,7 +262,7 @@ WP_HD c32 bin_unsplit(c32 y, c32 yp, c32 w)
 {
     const c32 A = {y.x + yp.x, y.y - yp.y};
     const float dx = y.x - yp.x, dy = y.y + yp.y;
-    return {A.x + (w.y * dx - w.x * dy), A.y + (w.y * dy + w.x * dx)};
+    return {fmaf(w.y, dx, fmaf(-w.x, dy, A.x)), fmaf(w.y, dy, fmaf(w.x, dx, A.y))};
 }
 
 // pre-twist of stage-0 inputs: v[u*R+t] *= thalf_j * exp(-i*pi*t/R) with

@@ -77,6 +77,20 @@ class BatchedConvolver:
             prev.stride(0) if prev is not None else 0, int(prev_len), _stream_ptr(torch)), "wp_conv_run_dev")
         return out
 
+    def run_mix(self, x, target, vol, in_len=None):
+        """Fused reverb + mix: jobs (2s, 2s+1) are the stereo source s; target is
+        [bus_left, bus_right] (1-D cuda tensors of equal length <= L+M), updated in
+        place like mixBuffers does; vol: one gain per source."""
+        import torch
+        assert x.is_cuda and x.dtype == torch.float32 and x.shape[0] == self.njobs and x.stride(1) == 1
+        assert len(target) == 2 and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in target)
+        n = int(x.shape[1]) if in_len is None else int(in_len)
+        tp = (C.c_void_p * 2)(target[0].data_ptr(), target[1].data_ptr())
+        g = (C.c_double * (self.njobs // 2))(*[float(v) for v in vol])
+        capi.check(capi.lib().wp_conv_mix_run_dev(self.handle, C.c_void_p(x.data_ptr()), x.stride(0), n, tp,
+                                                  int(target[0].shape[0]), g, _stream_ptr(torch)), "wp_conv_mix_run_dev")
+        return target
+
     def profile(self, enable=True):
         capi.check(capi.lib().wp_conv_profile(self.handle, 1 if enable else 0), "wp_conv_profile")
 

@@ -83,6 +83,15 @@ void wp_conv_destroy(wp_conv *c);
 int wp_conv_run_dev(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len, float *out_dev,
                     int64_t out_stride, const float *prev_dev, int64_t prev_stride, int64_t prev_len,
                     void *stream);
+/* Fused reverb + mix for a batch of stereo tracks (jobs 2s, 2s+1 = left, right of
+ * source s).  Produces what go() per channel (lib/convolve.js:570-583) followed by
+ *   mixBuffers(tgt, [[y_0,y_1],1,vol[0],0], [[y_2,y_3],1,vol[1],0], ...)
+ * (src/mix-buffers.js:49-52) produces in tgt_dev[0..1] (tl <= L+M frames, updated in
+ * place), bit-identically, but the per-track results are folded into the bus
+ * inside the inverse-transform kernel and never written to memory.  vol is a
+ * host array of njobs/2 gains. */
+int wp_conv_mix_run_dev(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len, float *const *tgt_dev,
+                        int64_t tl, const double *vol, void *stream);
 /* Device bytes of workspace a wp_conv holds. */
 int64_t wp_conv_workspace_bytes(const wp_conv *c);
 /* Measurement hook (no reference counterpart): when enabled, wp_conv_run_dev

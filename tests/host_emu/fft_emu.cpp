@@ -40,7 +40,7 @@ void run_stage(std::vector<c32> &regs, const std::vector<c32> &in, std::vector<c
     // barrier; phase 2: compute + store
     for (int tid = 0; tid < NT; tid++) {
         stage_compute<B, S, INV>(tid, &regs[tid * PT], tw);
-        stage_store<B, S, INV>(tid, &regs[tid * PT], [&](int i, c32 v, int) { out[lds_pad(i)] = v; });
+        stage_store<B, S, INV>(tid, &regs[tid * PT], [&](int i, c32 v, int, int) { out[lds_pad(i)] = v; });
     }
 }
 
@@ -98,7 +98,7 @@ double test_odft()
         stage_load<B, 0>(tid, v, [&](int n) { return c32{(float)r[2 * n], (float)r[2 * n + 1]}; });
         pre_twist<B>(tid, v, thalf.data());
         stage_compute<B, 0, false>(tid, v, T.tw);
-        stage_store<B, 0, false>(tid, v, [&](int i, c32 val, int) { a[lds_pad(i)] = val; });
+        stage_store<B, 0, false>(tid, v, [&](int i, c32 val, int, int) { a[lds_pad(i)] = val; });
     }
     run_stage<B, 1, false>(regs, a, b, T.tw);
     run_stage<B, 2, false>(regs, b, a, T.tw);
@@ -120,7 +120,7 @@ double test_odft()
     for (int tid = 0; tid < NT; tid++) stage_load<B, 2>(tid, &regs[tid * PT], [&](int i) { return b[lds_pad(i)]; });
     for (int tid = 0; tid < NT; tid++) {
         stage_compute<B, 2, true>(tid, &regs[tid * PT], T.tw);
-        stage_store<B, 2, true>(tid, &regs[tid * PT], [&](int i, c32 val, auto tt) {
+        stage_store<B, 2, true>(tid, &regs[tid * PT], [&](int i, c32 val, auto tt, auto) {
             out[i] = post_twist<B, int(tt)>(val, thalf[i & (B / R - 1)]);
         });
     }

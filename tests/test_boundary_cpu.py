@@ -95,7 +95,7 @@ def test_synthetic_ir_matches_oracle_generator(oracle):
 
 def test_fft_stage_code_host_emulation(tmp_path):
     exe = str(tmp_path / "fft_emu")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "host_emu", "fft_emu.cpp")])
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "host_emu", "fft_emu.cpp")])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "FAIL" not in out.stdout

@@ -144,3 +144,29 @@ def test_mix_full_size_properties(torch):
     ref = ((stem[0].double() + stem[1].double()) / 2).float()
     ref = (ref.double() + (stem[0].double() + stem[1].double()) / 2).float()
     assert torch.equal(mono[0], ref)
+
+
+@pytest.mark.parametrize("L,M,tracks,tl", [(9000, 5000, 5, 9000), (20000, 3000, 3, 23000), (4096, 4096, 2, 4097), (70000, 20000, 4, 65536)])
+def test_fused_reverb_mix_is_bit_identical_to_unfused(torch, L, M, tracks, tl):
+    """wp_conv_mix_run_dev == wp_conv_run_dev followed by wp_mix_dev, bit for bit
+    (same samples, same f64 fold, same source order), for ragged sizes, a
+    non-zero starting bus and tl shorter/longer than L."""
+    from dsp_amd import device
+    njobs = 2 * tracks
+    irs = torch.from_numpy(np.stack([device.synth_ir(M, 80), device.synth_ir(M, 81)])).cuda()
+    ir = device.DeviceIR(irs, L)
+    conv = device.BatchedConvolver(ir, [j % 2 for j in range(njobs)])
+    x = torch.empty((njobs, L), dtype=torch.float32, device="cuda")
+    for j in range(njobs):
+        device.synth_noise(x[j], 500 + j)
+    vol = [1.3 / (1 + t) for t in range(tracks)]
+    out = torch.empty((njobs, L + M + (L + M) % 2), dtype=torch.float32, device="cuda")
+    conv.run(x, out)
+    bus_a = torch.empty((2, tl), dtype=torch.float32, device="cuda")
+    device.synth_noise(bus_a[0], 9)
+    device.synth_noise(bus_a[1], 10)
+    bus_b = bus_a.clone()
+    device.DeviceMix([{"ch": [out[2 * t], out[2 * t + 1]], "rl": L + M, "sl": L + M, "vol": vol[t]} for t in range(tracks)]).run([bus_a[0], bus_a[1]])
+    conv.run_mix(x, [bus_b[0], bus_b[1]], vol)
+    torch.cuda.synchronize()
+    assert torch.equal(bus_a.view(torch.int32), bus_b.view(torch.int32))
