@@ -262,8 +262,7 @@ static int choose_PG(int P)
     if (P <= 8) return 8;
     if (P <= 12) return 12;
     if (P <= 16) return 16;
-    if (P <= 24) return 24;
-    return 12;
+    return 24;  // longer IRs run ceil(P/24) accumulating passes of 24 partitions
 }
 
 static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, int64_t M, int64_t L, hipStream_t s)

@@ -259,7 +259,7 @@ __global__ void k_hpack(const c32 *__restrict__ Zir, c32 *__restrict__ Hc, const
 
 // loads in flight per lane in k_mac (must divide PG so ring slots stay static)
 #ifndef WP_MAC_DEPTH
-#define WP_MAC_DEPTH(PG) ((PG) <= 12 ? (PG) : ((PG) == 24 ? 12 : 8))
+#define WP_MAC_DEPTH(PG) ((PG) <= 12 ? (PG) : ((PG) == 24 ? 6 : 8))
 #endif
 
 // ---------------------------------------------------------------------------
@@ -320,6 +320,20 @@ __global__ __launch_bounds__(256) void k_mac(const c32 *__restrict__ Z, c32 *__r
     c32 ring[D];
 #pragma unroll
     for (int d = 0; d < D; d++) ring[d] = ld(d);
+    // ACCUM (second and later partition groups add into W): the old W rows are
+    // prefetched through a ring of their own, D steps ahead, so the
+    // read-modify-write never waits on a dependent load.
+    const int t_last = tb - 1;
+    auto ldw = [&](int i) {
+        int tt = tau0 + i + p0;
+        tt = tt < ta ? ta : (tt > t_last ? t_last : tt);
+        return wj[(int64_t)tt * B];
+    };
+    c32 wring[D];
+    if (ACCUM) {
+#pragma unroll
+        for (int d = 0; d < D; d++) wring[d] = ldw(d);
+    }
 
     // one step; SLOT = i % PG.  STORE: 0 never (warm-up), 1 always, 2 if i < nsteps
     auto step = [&](int i, auto slot_c, auto store_c) {
@@ -328,6 +342,11 @@ __global__ __launch_bounds__(256) void k_mac(const c32 *__restrict__ Z, c32 *__r
         constexpr int rs = u % D;
         const c32 z = ring[rs];
         ring[rs] = ld(i + D);
+        c32 wold = {0.f, 0.f};
+        if constexpr (ACCUM) {
+            wold = wring[rs];
+            wring[rs] = ldw(i + D);
+        }
         const c32 zp = {__shfl_xor(z.x, 32), __shfl_xor(z.y, 32)};
         const c32 x = bin_split(z, zp, w);
         static_for<0, PG>([&](auto p) {
@@ -342,7 +361,7 @@ __global__ __launch_bounds__(256) void k_mac(const c32 *__restrict__ Z, c32 *__r
             c32 o = bin_unsplit(y, yp, w);
             if (STORE == 1 || i < nsteps) {
                 c32 *wo = wj + (int64_t)(tau0 + i + p0) * B;
-                if (ACCUM) o = o + *wo;
+                if (ACCUM) o = o + wold;
                 *wo = o;
             }
         }
