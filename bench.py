@@ -41,7 +41,7 @@ def parse():
                     help="write every track's reverb result and mix it in a second kernel (wp_conv_run_dev + wp_mix_dev) "
                          "instead of the fused reverb+mix entry point (wp_conv_mix_run_dev)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tracks", type=int, default=4, help="stereo tracks in the bounded CPU sample")
+    ap.add_argument("--cpu-tracks", type=int, default=20, help="stereo tracks in the bounded CPU sample")
     return ap.parse_args()
 
 
@@ -192,7 +192,7 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": avg,
                          "kernel_GBs": {k: alg[k] / (avg[k] * 1e-3) / 1e9 for k in avg if avg[k] > 0},
-                         "pipeline_compulsory_GBs": njobs * (4 * F + 4 * out_len) / (dt / K) / 1e9},
+                         "pipeline_compulsory_GBs": (njobs * 4 * F + (16 * F if fused else njobs * 4 * out_len)) / (dt / K) / 1e9},
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(F, M, a.cpu_tracks)

@@ -48,7 +48,7 @@ import json
 traffic = {}
 for k in acc:
     base = k.split("<")[0]
-    if base in ("k_fft_fwd", "k_mac", "k_fft_inv", "k_mix") and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
+    if base in ("k_fft_fwd", "k_mac", "k_fft_inv", "k_fft_inv_mix", "k_mix") and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
         f = acc[k]["FETCH_SIZE"][0] / acc[k]["FETCH_SIZE"][1]
         w = acc[k]["WRITE_SIZE"][0] / acc[k]["WRITE_SIZE"][1]
         if base == "k_fft_fwd" and f < 1e5:
