@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--unfused", action="store_true",
                     help="write every track's reverb result and mix it in a second kernel (wp_conv_run_dev + wp_mix_dev) "
                          "instead of the fused reverb+mix entry point (wp_conv_mix_run_dev)")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for rehearsing "
+                    "the multi-rank flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tracks", type=int, default=20, help="stereo tracks in the bounded CPU sample")
     return ap.parse_args()
@@ -79,9 +81,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world))
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            except TypeError:  # older signature without device_id
+                dist.init_process_group("nccl")
+        else:
+            dist.init_process_group(a.backend)
 
     F = int(round(a.seconds * a.rate))
     M = int(round(a.ir_seconds * a.rate))
@@ -148,7 +157,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

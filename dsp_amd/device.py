@@ -174,5 +174,10 @@ def reduce_master_bus(bus, dist, dst=0):
     `dst` (RCCL over xGMI on GPUs, gloo on CPU tensors).  `bus` is a single
     tensor [channels, frames]; one message per call."""
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(bus, dst=dst, op=dist.ReduceOp.SUM)
+        if bus.is_cuda and dist.get_backend() == "gloo":  # rehearsal without RCCL: stage through the host
+            host = bus.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            bus.copy_(host)
+        else:
+            dist.reduce(bus, dst=dst, op=dist.ReduceOp.SUM)
     return bus

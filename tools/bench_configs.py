@@ -53,10 +53,20 @@ def c2():
     capi.lib().wp_reverb_destroy(rv)
     # host-pointer path (what the JavaScript shim calls): includes H2D of 2 x L and D2H of 2 x (L+M) floats
     from dsp_amd import impulse
-    from oracle import oracle as o  # only for the stub context object
-    store = {}
-    xs = [x[0].cpu().numpy(), x[1].cpu().numpy()]
-    ctx = o.StubContext(xs, 0, {"ir": [irs[0], irs[1]]}, store)
+
+    class Ctx:  # the surface of src/context.js the wrapper uses
+        def __init__(self, buffer):
+            self.buffer, self.n, self.store = buffer, 0, {}
+
+        def sample(self, url):
+            return [irs[0], irs[1]]
+
+        def get(self, k):
+            return self.store.get(k, False)
+
+        def set(self, k, v, ttl=None):
+            self.store[k] = v
+    ctx = Ctx([x[0].cpu().numpy(), x[1].cpu().numpy()])
     fn = impulse.impulse_reverb_stereo(ctx, "ir")
     t_host = timed(lambda: fn(ctx), 50, 5)
     return {"config": "c2 stereo reverb, L=M=96000", "us_per_bar_device_resident": t_dev * 1e6,
