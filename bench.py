@@ -6,7 +6,9 @@ Workload (BASELINE.json configs[2], the one the metric's target is quoted on):
 channel convolved with a 2 s IR (M = 96 000; one `go` of L = F per channel-job,
 lib/convolve.js:570-583), then all 256 stereo results summed into one stereo
 master bus (src/mix-buffers.js tuple form, vol = 1/256).  One "step" = that
-whole pass.  Inputs are synthetic integer-hash noise already resident in HBM
+whole pass: wp_conv_run_dev (every job's full L+M result is written) followed by
+wp_mix_dev.  The fused entry point wp_conv_mix_run_dev is measured too and
+reported in an extra field.  Inputs are synthetic integer-hash noise already resident in HBM
 when the timed region starts.  With --gpus N each rank owns 256 tracks (weak
 scaling) and the rank-local partial buses are combined by one RCCL reduce.
 
@@ -37,9 +39,10 @@ def parse():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--ir-seconds", type=float, default=2.0)
     ap.add_argument("--rate", type=int, default=48000)
-    ap.add_argument("--unfused", action="store_true",
-                    help="write every track's reverb result and mix it in a second kernel (wp_conv_run_dev + wp_mix_dev) "
-                         "instead of the fused reverb+mix entry point (wp_conv_mix_run_dev)")
+    ap.add_argument("--fused", action="store_true",
+                    help="time the fused reverb+mix entry point (wp_conv_mix_run_dev: same bus, bit for bit, but the "
+                         "per-track results are never written) as the headline instead of wp_conv_run_dev + wp_mix_dev")
+    ap.add_argument("--no-fused-extra", action="store_true", help="skip the extra fused-path measurement")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for rehearsing "
                     "the multi-rank flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -109,7 +112,7 @@ def main():
         dev.synth_noise(x[j], 1000 + 2 * (t_lo + j // 2) + (j % 2))
     bus = torch.zeros((2, F), dtype=torch.float32, device="cuda")
     vol = [1.0 / 256] * tracks
-    fused = not a.unfused
+    fused = a.fused
     if fused:
         kern_ms = {"k_fft_fwd": 0.0, "k_mac": 0.0, "k_fft_inv_mix": 0.0}
     else:
@@ -161,9 +164,38 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # secondary measurement, outside the headline's timed region: the fused reverb+mix path
+    fused_extra = None
+    if not fused and not a.no_fused_extra:
+        def fstep():
+            bus.zero_()
+            conv.run_mix(x, [bus[0], bus[1]], vol)
+            if world > 1:
+                dev.reduce_master_bus(bus, dist, dst=0)
+        fstep()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        f0 = time.perf_counter()
+        for _ in range(a.steps):
+            fstep()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        fdt = time.perf_counter() - f0
+        if world > 1:
+            ft = torch.tensor([fdt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+            dist.all_reduce(ft, op=dist.ReduceOp.MAX)
+            fdt = float(ft.item())
+        fused_extra = {"ms_per_step": fdt / a.steps * 1e3,
+                       "bus_input_Msamples_per_s": world * njobs * F * a.steps / fdt / 1e6,
+                       "note": "wp_conv_mix_run_dev: identical bus, per-track results and the M-sample tails beyond the "
+                               "bus are not produced, so it is reported beside the headline, not as it"}
+
     if rank == 0:
         K = a.steps
-        total_samples = world * njobs * out_len * K
+        # samples the timed path produced: every job's L+M result (unfused), or the F frames per job that reach the bus (fused)
+        total_samples = world * njobs * (F if fused else out_len) * K
         B = capi_info(conv, 2)
         T = capi_info(conv, 1)
         # blocks each kernel touches: the fused path only needs the blocks that reach the bus (tl = F)
@@ -203,6 +235,8 @@ def main():
                          "kernel_GBs": {k: alg[k] / (avg[k] * 1e-3) / 1e9 for k in avg if avg[k] > 0},
                          "pipeline_compulsory_GBs": (njobs * 4 * F + (16 * F if fused else njobs * 4 * out_len)) / (dt / K) / 1e9},
         }
+        if fused_extra is not None:
+            res["fused_path"] = fused_extra
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(F, M, a.cpu_tracks)
         print(json.dumps(res), flush=True)
