@@ -15,6 +15,22 @@
 
 namespace wp {
 
+// streaming accesses: every spectrum row is written once and read once by a later
+// kernel, tens of gigabytes apart, so it is marked non-temporal
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ c32 ld_nt(const c32 *p)
+{
+    const v2f t = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
+    return c32{t.x, t.y};
+}
+__device__ __forceinline__ void st_nt(c32 *p, c32 v)
+{
+    v2f t;
+    t.x = v.x;
+    t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<v2f *>(p));
+}
+
 // ---------------------------------------------------------------------------
 template <int B>
 __device__ __forceinline__ TwTables<B> load_tables(const c32 *__restrict__ g, c32 *tws, int tid)
@@ -86,7 +102,7 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_fwd(const float *__r
     pre_twist<B>(tid, v, tables + table_thalf_offset(B));
     middle_stages<B, false>(tid, v, lds, tw);
     c32 *z = Z + ((int64_t)job * T + t) * B;
-    stage_store<B, 2, false>(tid, v, [&](int i, c32 val, int, int) { z[i] = val; });
+    stage_store<B, 2, false>(tid, v, [&](int i, c32 val, int, int) { st_nt(z + i, val); });
 }
 
 // ---------------------------------------------------------------------------
@@ -110,7 +126,7 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv(const c32 *__res
 
     const c32 *w = W + ((int64_t)job * T + t) * B;
     c32 v[FftPlan<B>::PT];
-    stage_load<B, 0>(tid, v, [&](int n) { return w[n]; });
+    stage_load<B, 0>(tid, v, [&](int n) { return ld_nt(w + n); });
     middle_stages<B, true>(tid, v, lds, tw);
 
     constexpr int R = FftPlan<B>::radix(2);
@@ -131,7 +147,7 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv(const c32 *__res
                     val.x += p.x;
                     val.y += p.y;
                 }
-                *reinterpret_cast<c32 *>(y + o) = val;
+                st_nt(reinterpret_cast<c32 *>(y + o), val);
             } else {
                 if (o < out_len) y[o] = val.x + ((pv && o < prev_len) ? pv[o] : 0.0f);
                 if (o + 1 < out_len) y[o + 1] = val.y + ((pv && o + 1 < prev_len) ? pv[o + 1] : 0.0f);
@@ -311,7 +327,7 @@ __global__ __launch_bounds__(256) void k_mac(const c32 *__restrict__ Z, c32 *__r
     auto ld = [&](int i) {         // unconditional: clamped address, zero-selected value
         const int tau = tau0 + i;
         const int tc = tau < 0 ? 0 : (tau > tin_last ? tin_last : tau);
-        c32 a = zj[(int64_t)tc * B];
+        c32 a = ld_nt(zj + (int64_t)tc * B);
         const bool ok = (tau == tc);
         a.x = ok ? a.x : 0.0f;
         a.y = ok ? a.y : 0.0f;
@@ -362,7 +378,7 @@ __global__ __launch_bounds__(256) void k_mac(const c32 *__restrict__ Z, c32 *__r
             if (STORE == 1 || i < nsteps) {
                 c32 *wo = wj + (int64_t)(tau0 + i + p0) * B;
                 if (ACCUM) o = o + wold;
-                *wo = o;
+                st_nt(wo, o);
             }
         }
     };
