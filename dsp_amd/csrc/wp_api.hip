@@ -193,7 +193,7 @@ static int get_tables(int dev, int B, const c32 **out)
         for (int b = 0; b < B / 256; b++)
             h[512 + b] = {(float)cos(2 * pi * b * 256.0 / B), (float)-sin(2 * pi * b * 256.0 / B)};
         const int ho = table_thalf_offset(B), wo = table_wsplit_offset(B);
-        for (int j = 0; j < 256; j++) h[ho + j] = {(float)cos(pi * j / B), (float)-sin(pi * j / B)};
+        for (int j = 0; j < 512; j++) h[ho + j] = {(float)cos(pi * j / B), (float)-sin(pi * j / B)};
         for (int q = 0; q < B; q++) h[wo + q] = {(float)cos(pi * (q + 0.5) / B), (float)-sin(pi * (q + 0.5) / B)};
         DevTables t;
         HIPCHK(hipMalloc((void **)&t.d, sizeof(c32) * n));
@@ -247,9 +247,11 @@ static int choose_B(int64_t L, int64_t M)
 {
     if (const char *e = getenv("WPDSP_B")) {
         const int b = atoi(e);
-        if (b == 1024 || b == 2048 || b == 4096) return b;
+        if (b == 1024 || b == 2048 || b == 4096 || b == 8192) return b;
     }
-    return (L + M <= 8192) ? 1024 : 4096;
+    if (L + M <= 8192) return 1024;
+    // one MAC pass covers 24 partitions: IRs longer than 24*4096 samples use the larger partition
+    return (M > 24 * 4096) ? 8192 : 4096;
 }
 
 static int choose_PG(int P)

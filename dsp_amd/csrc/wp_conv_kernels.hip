@@ -228,14 +228,24 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv_mix(const c32 *_
     };
 
     // two register sets: the next source's spectrum is in flight while this one is transformed
-    c32 v[PT], vn[PT];
-    fetch(0, vn);
+    // (with 32 points per thread a second set would spill, so that plan loads in place)
+    if constexpr (PT <= 16) {
+        c32 v[PT], vn[PT];
+        fetch(0, vn);
 #pragma unroll 1
-    for (int s = 0; s < nsrc; s++) {
+        for (int s = 0; s < nsrc; s++) {
 #pragma unroll
-        for (int i = 0; i < PT; i++) v[i] = vn[i];
-        fetch(s + 1, vn);
-        transform_fold(v, vol[s]);
+            for (int i = 0; i < PT; i++) v[i] = vn[i];
+            fetch(s + 1, vn);
+            transform_fold(v, vol[s]);
+        }
+    } else {
+        c32 v[PT];
+#pragma unroll 1
+        for (int s = 0; s < nsrc; s++) {
+            fetch(s, v);
+            transform_fold(v, vol[s]);
+        }
     }
 
     each_out([&](auto slot, int64_t o) {
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(256) void k_mac(const c32 *__restrict__ Z, c32 *__r
                                              const int32_t *__restrict__ job_irch, int B, int T, int Tout, int Tin,
                                              int Pp, int p0, int tchunk)
 {
-    constexpr int D = WP_MAC_DEPTH(PG);
+    constexpr int D = (ACCUM && PG == 24) ? 4 : WP_MAC_DEPTH(PG);  // the accumulating pass carries a second ring: keep it at 3 waves per SIMD
     static_assert(PG % D == 0, "ring");
     const int slot = blockIdx.x * 256 + threadIdx.x;  // grid.x * 256 == B
     const int k = lane_bin(slot, B);
@@ -426,6 +436,7 @@ hipError_t launch_fft_fwd(int B, bool irmode, const float *in, int64_t in_stride
     case 1024: return launch_fwd_t<1024>(irmode, in, in_stride, in_len, Z, T, nblocks, njobs, tables, s);
     case 2048: return launch_fwd_t<2048>(irmode, in, in_stride, in_len, Z, T, nblocks, njobs, tables, s);
     case 4096: return launch_fwd_t<4096>(irmode, in, in_stride, in_len, Z, T, nblocks, njobs, tables, s);
+    case 8192: return launch_fwd_t<8192>(irmode, in, in_stride, in_len, Z, T, nblocks, njobs, tables, s);
     }
     return hipErrorInvalidValue;
 }
@@ -452,6 +463,7 @@ hipError_t launch_fft_inv(int B, const c32 *W, int T, int njobs, float *out, int
     case 1024: return launch_inv_t<1024>(W, T, njobs, out, out_stride, out_len, prev, prev_stride, prev_len, tables, s);
     case 2048: return launch_inv_t<2048>(W, T, njobs, out, out_stride, out_len, prev, prev_stride, prev_len, tables, s);
     case 4096: return launch_inv_t<4096>(W, T, njobs, out, out_stride, out_len, prev, prev_stride, prev_len, tables, s);
+    case 8192: return launch_inv_t<8192>(W, T, njobs, out, out_stride, out_len, prev, prev_stride, prev_len, tables, s);
     }
     return hipErrorInvalidValue;
 }
@@ -476,6 +488,7 @@ hipError_t launch_fft_inv_mix(int B, const c32 *W, int T, int nblocks, int nsrc,
     case 1024: return launch_inv_mix_t<1024>(W, T, nblocks, nsrc, bus0, bus1, tl, vol, tables, s);
     case 2048: return launch_inv_mix_t<2048>(W, T, nblocks, nsrc, bus0, bus1, tl, vol, tables, s);
     case 4096: return launch_inv_mix_t<4096>(W, T, nblocks, nsrc, bus0, bus1, tl, vol, tables, s);
+    case 8192: return launch_inv_mix_t<8192>(W, T, nblocks, nsrc, bus0, bus1, tl, vol, tables, s);
     }
     return hipErrorInvalidValue;
 }

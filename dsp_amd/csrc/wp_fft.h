@@ -51,35 +51,39 @@ WP_HD void static_for(F &&f)
     }
 }
 
-// cos(2*pi*i/32), first octant + symmetry; usable in constant expressions
-constexpr float w32_cos(int i)
+// cos(2*pi*i/64) from a quarter-wave table + symmetry; usable in constant expressions
+constexpr float w64_cos(int i)
 {
-    constexpr float q[9] = {1.0f,           0.98078528040f, 0.92387953251f,
-                            0.83146961230f, 0.70710678119f, 0.55557023302f,
-                            0.38268343237f, 0.19509032202f, 0.0f};
-    i &= 31;
-    return i <= 8 ? q[i] : i <= 16 ? -q[16 - i] : i <= 24 ? -q[i - 16] : q[32 - i];
+    constexpr float q[17] = {1.00000000000f, 0.99518472667f, 0.98078528040f, 0.95694033573f, 0.92387953251f, 0.88192126435f, 0.83146961230f, 0.77301045336f, 0.70710678119f, 0.63439328416f, 0.55557023302f, 0.47139673683f, 0.38268343237f, 0.29028467725f, 0.19509032202f, 0.09801714033f, 0.00000000000f};
+    i &= 63;
+    return i <= 16 ? q[i] : i <= 32 ? -q[32 - i] : i <= 48 ? -q[i - 32] : q[64 - i];
 }
-constexpr float w32_sin(int i) { return w32_cos(i + 24); }
+constexpr float w64_sin(int i) { return w64_cos(i + 48); }
 
-// a * exp(-2*pi*i*IDX/32)  (forward) or a * exp(+2*pi*i*IDX/32)  (INV)
+// a * exp(-2*pi*i*IDX/64)  (forward) or a * exp(+2*pi*i*IDX/64)  (INV)
+template <int IDX, bool INV>
+WP_HD c32 mul_w64(c32 a)
+{
+    constexpr int i = IDX & 63;
+    if constexpr (i == 0) {
+        return a;
+    } else if constexpr (i == 32) {
+        return {-a.x, -a.y};
+    } else if constexpr (i == 16) {  // -i forward, +i inverse
+        return INV ? c32{-a.y, a.x} : c32{a.y, -a.x};
+    } else if constexpr (i == 48) {
+        return INV ? c32{a.y, -a.x} : c32{-a.y, a.x};
+    } else {
+        constexpr float c = w64_cos(i);
+        constexpr float s = INV ? w64_sin(i) : -w64_sin(i);
+        return {fmaf(a.x, c, -(a.y * s)), fmaf(a.x, s, a.y * c)};
+    }
+}
+// a * exp(-/+ 2*pi*i*IDX/32)
 template <int IDX, bool INV>
 WP_HD c32 mul_w32(c32 a)
 {
-    constexpr int i = IDX & 31;
-    if constexpr (i == 0) {
-        return a;
-    } else if constexpr (i == 16) {
-        return {-a.x, -a.y};
-    } else if constexpr (i == 8) {  // -i forward, +i inverse
-        return INV ? c32{-a.y, a.x} : c32{a.y, -a.x};
-    } else if constexpr (i == 24) {
-        return INV ? c32{a.y, -a.x} : c32{-a.y, a.x};
-    } else {
-        constexpr float c = w32_cos(i);
-        constexpr float s = INV ? w32_sin(i) : -w32_sin(i);
-        return {fmaf(a.x, c, -(a.y * s)), fmaf(a.x, s, a.y * c)};
-    }
+    return mul_w64<2 * IDX, INV>(a);
 }
 
 template <bool INV>
@@ -147,6 +151,11 @@ template <>
 struct FftPlan<4096> {
     static constexpr int PT = 16, NSTAGE = 3;
     static constexpr int radix(int) { return 16; }
+};
+template <>
+struct FftPlan<8192> {
+    static constexpr int PT = 32, NSTAGE = 3;
+    static constexpr int radix(int s) { return s == 2 ? 32 : 16; }
 };
 template <int B>
 constexpr int plan_ns(int s)  // product of the radices before stage s
@@ -285,8 +294,8 @@ template <int B, int T_>
 WP_HD c32 post_twist(c32 val, c32 thalf_j)
 {
     constexpr int R = FftPlan<B>::radix(FftPlan<B>::NSTAGE - 1);
-    static_assert(R == 16 || R == 8 || R == 4, "last-stage radix");
-    return cmul(val, mul_w32<T_ * (16 / R), true>(cconj(thalf_j)));
+    static_assert(R == 32 || R == 16 || R == 8 || R == 4, "last-stage radix");
+    return cmul(val, mul_w64<T_ * (32 / R), true>(cconj(thalf_j)));
 }
 
 }  // namespace wp

@@ -85,8 +85,8 @@ double test_odft()
 {
     Tables<B> T;
     constexpr int PT = FftPlan<B>::PT, NT = B / PT;
-    std::vector<c32> thalf(256), wbin(B);
-    for (int j = 0; j < 256; j++) thalf[j] = {(float)cos(M_PI * j / B), (float)-sin(M_PI * j / B)};
+    std::vector<c32> thalf(512), wbin(B);
+    for (int j = 0; j < 512; j++) thalf[j] = {(float)cos(M_PI * j / B), (float)-sin(M_PI * j / B)};
     for (int k = 0; k < B; k++) wbin[k] = {(float)cos(M_PI * (k + 0.5) / B), (float)-sin(M_PI * (k + 0.5) / B)};
     std::vector<double> r(2 * B);
     srand(11 * B);
@@ -149,5 +149,8 @@ int main()
     CHECK("odd-frequency rt 1024", test_odft<1024>(), 2e-6);
     CHECK("odd-frequency rt 2048", test_odft<2048>(), 2e-6);
     CHECK("odd-frequency rt 4096", test_odft<4096>(), 2e-6);
+    CHECK("fft 8192 fwd", (test_fft<8192, false>()), 2e-6);
+    CHECK("fft 8192 inv", (test_fft<8192, true>()), 2e-6);
+    CHECK("odd-frequency rt 8192", test_odft<8192>(), 2e-6);
     return bad;
 }

@@ -42,11 +42,11 @@ def test_synth_noise_device_matches_oracle(torch, oracle):
 
 
 @pytest.mark.parametrize("L,M,njobs", [(5000, 1200, 6), (20000, 9000, 5), (70000, 30000, 3), (4096, 4096, 4), (100, 50000, 2),
-                                        (3000, 110000, 2), (1, 1, 1), (700, 7400, 3)])
+                                        (3000, 110000, 2), (1, 1, 1), (700, 7400, 3), (20000, 210000, 2)])
 def test_batched_convolver_vs_oracle(torch, oracle, L, M, njobs):
     """Ragged sizes (L, M not multiples of the partition), several jobs, IR channel map;
     (3000, 110000) needs 27 partitions = two accumulating MAC passes; (1, 1) is the
-    smallest legal FFT; (700, 7400) is the small-partition plan with 8 partitions."""
+    smallest legal FFT; (20000, 210000) uses the 8192-point plan with two passes; (700, 7400) is the small-partition plan with 8 partitions."""
     from dsp_amd import device
     irs = np.stack([oracle.synth_ir(M, 40), oracle.synth_ir(M, 41)])
     ir = device.DeviceIR(torch.from_numpy(irs).cuda(), L)
