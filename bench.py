@@ -39,9 +39,10 @@ def parse():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--ir-seconds", type=float, default=2.0)
     ap.add_argument("--rate", type=int, default=48000)
-    ap.add_argument("--fused", action="store_true",
-                    help="time the fused reverb+mix entry point (wp_conv_mix_run_dev: same bus, bit for bit, but the "
-                         "per-track results are never written) as the headline instead of wp_conv_run_dev + wp_mix_dev")
+    ap.add_argument("--path", choices=["onepass", "twopass", "fused"], default="onepass",
+                    help="onepass: wp_conv_run_mix_dev (every job's L+M result written AND the bus folded in the same "
+                         "kernel); twopass: wp_conv_run_dev then wp_mix_dev; fused: wp_conv_mix_run_dev (bus only, "
+                         "per-track results never written).  All three give the same bus, bit for bit.")
     ap.add_argument("--no-fused-extra", action="store_true", help="skip the extra fused-path measurement")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for rehearsing "
                     "the multi-rank flow on a box with fewer GPUs than ranks)")
@@ -112,9 +113,13 @@ def main():
         dev.synth_noise(x[j], 1000 + 2 * (t_lo + j // 2) + (j % 2))
     bus = torch.zeros((2, F), dtype=torch.float32, device="cuda")
     vol = [1.0 / 256] * tracks
-    fused = a.fused
+    fused = a.path == "fused"
+    onepass = a.path == "onepass"
     if fused:
         kern_ms = {"k_fft_fwd": 0.0, "k_mac": 0.0, "k_fft_inv_mix": 0.0}
+    elif onepass:
+        out = torch.empty((njobs, stride_out), dtype=torch.float32, device="cuda")
+        kern_ms = {"k_fft_fwd": 0.0, "k_mac": 0.0, "k_fft_inv_mix_w": 0.0}
     else:
         out = torch.empty((njobs, stride_out), dtype=torch.float32, device="cuda")
         mix = dev.DeviceMix([{"ch": [out[2 * t], out[2 * t + 1]], "rl": F, "sl": F, "vol": vol[t], "o": 0}
@@ -127,6 +132,8 @@ def main():
         bus.zero_()
         if fused:
             conv.run_mix(x, [bus[0], bus[1]], vol)
+        elif onepass:
+            conv.run_and_mix(x, out, [bus[0], bus[1]], vol)
         else:
             conv.run(x, out)
             ev[0].record()
@@ -140,6 +147,8 @@ def main():
             kern_ms["k_mac"] += m
             if fused:
                 kern_ms["k_fft_inv_mix"] += i
+            elif onepass:
+                kern_ms["k_fft_inv_mix_w"] += i
             else:
                 ev[1].synchronize()
                 kern_ms["k_fft_inv"] += i
@@ -207,6 +216,7 @@ def main():
             "k_mac": njobs * (8 * B * Tin + 8 * B * Tout),
             "k_fft_inv": njobs * (8 * B * T + 4 * out_len),
             "k_fft_inv_mix": njobs * 8 * B * Tout + 2 * 2 * 4 * F,
+            "k_fft_inv_mix_w": njobs * (8 * B * T + 4 * out_len) + 2 * 2 * 4 * F,
             "k_mix": F * (4 * 2 * tracks + 2 * 4 * 2),
         }
         avg = {k: v / K for k, v in kern_ms.items()}
@@ -227,7 +237,8 @@ def main():
             "config": {"workload": "batched reverb+mix: %d stereo tracks/GPU x %.0f s @ %d Hz x %.0f s stereo IR, "
                                    "one go() per channel-job then mixBuffers into a stereo bus" % (tracks, a.seconds, a.rate, a.ir_seconds),
                        "tracks_per_gpu": tracks, "frames": F, "ir_len": M, "partition": B, "blocks": T,
-                       "path": "fused reverb+mix (wp_conv_mix_run_dev)" if fused else "wp_conv_run_dev + wp_mix_dev",
+                       "path": {"fused": "wp_conv_mix_run_dev (bus only)", "onepass": "wp_conv_run_mix_dev (all go() results + bus in one pass)",
+                                "twopass": "wp_conv_run_dev + wp_mix_dev"}[a.path],
                        "parallelism": "tracks sharded over %d GPU(s), RCCL reduce of the bus" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

@@ -48,6 +48,8 @@ PROTOTYPES = {
                                   C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "wp_conv_mix_run_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.c_int64,
                                       f64p, C.c_void_p]),
+    "wp_conv_run_mix_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                      C.POINTER(C.c_void_p), C.c_int64, f64p, C.c_void_p]),
     "wp_conv_workspace_bytes": (C.c_int64, [C.c_void_p]),
     "wp_conv_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "wp_conv_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),

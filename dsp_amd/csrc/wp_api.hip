@@ -530,29 +530,48 @@ extern "C" int wp_conv_run_dev(wp_conv *c, const float *in_dev, int64_t in_strid
     return WP_OK;
 }
 
-extern "C" int wp_conv_mix_run_dev(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len,
-                                   float *const *tgt_dev, int64_t tl, const double *vol, void *stream)
+static int conv_mix_common(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len, float *out_dev,
+                           int64_t out_stride, float *const *tgt_dev, int64_t tl, const double *vol, hipStream_t s,
+                           const char *who)
 {
-    if (int rc = need_device()) return rc;
     if (!c || !tgt_dev || !tgt_dev[0] || !tgt_dev[1] || !vol || (!in_dev && in_len > 0))
-        return fail(WP_ERR_INVALID, "wp_conv_mix_run_dev: null argument");
+        return fail(WP_ERR_INVALID, "%s: null argument", who);
     const wp_ir *ir = c->ir;
-    if (c->njobs % 2) return fail(WP_ERR_INVALID, "wp_conv_mix_run_dev: needs an even number of jobs (stereo sources)");
-    if (tl < 0 || tl > ir->L + ir->M) return fail(WP_ERR_INVALID, "wp_conv_mix_run_dev: target length %lld exceeds the result length %lld", (long long)tl, (long long)(ir->L + ir->M));
+    if (c->njobs % 2) return fail(WP_ERR_INVALID, "%s: needs an even number of jobs (stereo sources)", who);
+    if (tl < 0 || tl > ir->L + ir->M) return fail(WP_ERR_INVALID, "%s: target length %lld exceeds the result length %lld", who, (long long)tl, (long long)(ir->L + ir->M));
     if (int rc = check_in_len(ir, in_len)) return rc;
-    if (tl == 0) return WP_OK;
-    hipStream_t s = (hipStream_t)stream;
+    if (tl == 0 && !out_dev) return WP_OK;
     const int nsrc = c->njobs / 2;
     if (!c->vol_dev) HIPCHK(hipMalloc((void **)&c->vol_dev, sizeof(double) * nsrc));
     HIPCHK(hipMemcpyAsync(c->vol_dev, vol, sizeof(double) * nsrc, hipMemcpyHostToDevice, s));
-    const int Tout = (int)((tl + ir->B - 1) / ir->B);
+    // with per-job results every output block is needed; otherwise only those that reach the bus
+    const int Tout = out_dev ? c->T : (int)((tl + ir->B - 1) / ir->B);
     if (int rc = conv_front(c, in_dev, in_stride, in_len, Tout, s)) return rc;
-    HIPCHK(launch_fft_inv_mix(ir->B, c->W, c->T, Tout, nsrc, tgt_dev[0], tgt_dev[1], tl, c->vol_dev, ir->tables, s));
+    HIPCHK(launch_fft_inv_mix(ir->B, c->W, c->T, Tout, nsrc, tgt_dev[0], tgt_dev[1], tl, c->vol_dev, out_dev, out_stride,
+                              ir->L + ir->M, ir->tables, s));
     if (c->prof) {
         HIPCHK(hipEventRecord(c->ev[3], s));
         c->prof_valid = true;
     }
     return WP_OK;
+}
+
+extern "C" int wp_conv_mix_run_dev(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len,
+                                   float *const *tgt_dev, int64_t tl, const double *vol, void *stream)
+{
+    if (int rc = need_device()) return rc;
+    return conv_mix_common(c, in_dev, in_stride, in_len, nullptr, 0, tgt_dev, tl, vol, (hipStream_t)stream,
+                           "wp_conv_mix_run_dev");
+}
+
+extern "C" int wp_conv_run_mix_dev(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len, float *out_dev,
+                                   int64_t out_stride, float *const *tgt_dev, int64_t tl, const double *vol,
+                                   void *stream)
+{
+    if (int rc = need_device()) return rc;
+    if (!out_dev) return fail(WP_ERR_INVALID, "wp_conv_run_mix_dev: null output");
+    return conv_mix_common(c, in_dev, in_stride, in_len, out_dev, out_stride, tgt_dev, tl, vol, (hipStream_t)stream,
+                           "wp_conv_run_mix_dev");
 }
 
 extern "C" int wp_convolve(wp_ir *ir, int ch, const float *in, int64_t in_len, float *out)

@@ -171,11 +171,13 @@ __device__ __forceinline__ float mix_fold(float acc, float y, double vol)
     return (float)((double)acc + (double)y * vol);  // this file is built with -ffp-contract=off
 }
 
-template <int B>
+// WRITE: also store every job's samples (the go() results, L+M per job) while folding.
+template <int B, bool WRITE>
 __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv_mix(const c32 *__restrict__ W, int T, int nsrc,
                                                                    float *__restrict__ bus0, float *__restrict__ bus1,
                                                                    int64_t tl, const double *__restrict__ vol,
-                                                                   const c32 *__restrict__ tables)
+                                                                   float *__restrict__ out, int64_t out_stride,
+                                                                   int64_t out_len, const c32 *__restrict__ tables)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
@@ -190,6 +192,7 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv_mix(const c32 *_
     const c32 *thalf = tables + table_thalf_offset(B);
     const int64_t o0 = (int64_t)t * B;
     const bool full = (o0 + B <= tl) && ((reinterpret_cast<uintptr_t>(bus + o0) & 7) == 0);
+    const bool folds = o0 < tl;  // blocks past the end of the bus only produce per-job samples
 
     // bus accumulators: sample pair `slot` of this thread sits at o0 + 2*(i - B/2), i = j + tt*NS
     c32 acc[NO];
@@ -214,14 +217,27 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv_mix(const c32 *_
         const c32 *w = W + ((int64_t)(2 * (src < nsrc ? src : nsrc - 1) + ch) * T + t) * B;
         stage_load<B, 0>(tid, v, [&](int n) { return w[n]; });
     };
-    auto transform_fold = [&](c32 *v, double g) {
+    auto transform_fold = [&](c32 *v, int src, double g) {
         middle_stages<B, true>(tid, v, lds, tw);
+        float *y = WRITE ? out + (int64_t)(2 * src + ch) * out_stride : nullptr;
+        const bool fullw = WRITE && (o0 + B <= out_len) && ((reinterpret_cast<uintptr_t>(y + o0) & 7) == 0);
         stage_store<B, 2, true>(tid, v, [&](int i, c32 val, auto tt, auto u) {
             if constexpr (int(tt) >= R / 2) {
                 val = post_twist<B, int(tt)>(val, thalf[i & (NS - 1)]);
-                constexpr int slot = int(u) * (R / 2) + int(tt) - R / 2;
-                acc[slot].x = mix_fold(acc[slot].x, val.x, g);
-                acc[slot].y = mix_fold(acc[slot].y, val.y, g);
+                if constexpr (WRITE) {
+                    const int64_t o = o0 + 2 * (int64_t)(i - B / 2);
+                    if (fullw) {
+                        st_nt(reinterpret_cast<c32 *>(y + o), val);
+                    } else {
+                        if (o < out_len) y[o] = val.x;
+                        if (o + 1 < out_len) y[o + 1] = val.y;
+                    }
+                }
+                if (folds) {
+                    constexpr int slot = int(u) * (R / 2) + int(tt) - R / 2;
+                    acc[slot].x = mix_fold(acc[slot].x, val.x, g);
+                    acc[slot].y = mix_fold(acc[slot].y, val.y, g);
+                }
             }
         });
         __syncthreads();  // every lane is done reading LDS before the next transform overwrites it
@@ -237,18 +253,18 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv_mix(const c32 *_
 #pragma unroll
             for (int i = 0; i < PT; i++) v[i] = vn[i];
             fetch(s + 1, vn);
-            transform_fold(v, vol[s]);
+            transform_fold(v, s, vol[s]);
         }
     } else {
         c32 v[PT];
 #pragma unroll 1
         for (int s = 0; s < nsrc; s++) {
             fetch(s, v);
-            transform_fold(v, vol[s]);
+            transform_fold(v, s, vol[s]);
         }
     }
 
-    each_out([&](auto slot, int64_t o) {
+    if (folds) each_out([&](auto slot, int64_t o) {
         if (full) {
             *reinterpret_cast<c32 *>(bus + o) = acc[slot];
         } else {
@@ -470,25 +486,33 @@ hipError_t launch_fft_inv(int B, const c32 *W, int T, int njobs, float *out, int
 
 template <int B>
 static hipError_t launch_inv_mix_t(const c32 *W, int T, int nblocks, int nsrc, float *bus0, float *bus1, int64_t tl,
-                                   const double *vol, const c32 *tables, hipStream_t s)
+                                   const double *vol, float *out, int64_t out_stride, int64_t out_len,
+                                   const c32 *tables, hipStream_t s)
 {
     if (fft_lds_bytes<B>() > 48 * 1024) {
-        hipError_t e = set_lds_attr<B>((const void *)k_fft_inv_mix<B>);
+        hipError_t e = out ? set_lds_attr<B>((const void *)k_fft_inv_mix<B, true>)
+                           : set_lds_attr<B>((const void *)k_fft_inv_mix<B, false>);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_fft_inv_mix<B>), dim3(nblocks, 2), dim3(B / FftPlan<B>::PT), fft_lds_bytes<B>(), s, W, T, nsrc,
-                       bus0, bus1, tl, vol, tables);
+    const dim3 grid(nblocks, 2), block(B / FftPlan<B>::PT);
+    if (out)
+        hipLaunchKernelGGL((k_fft_inv_mix<B, true>), grid, block, fft_lds_bytes<B>(), s, W, T, nsrc, bus0, bus1, tl, vol,
+                           out, out_stride, out_len, tables);
+    else
+        hipLaunchKernelGGL((k_fft_inv_mix<B, false>), grid, block, fft_lds_bytes<B>(), s, W, T, nsrc, bus0, bus1, tl, vol,
+                           out, out_stride, out_len, tables);
     return hipGetLastError();
 }
 
 hipError_t launch_fft_inv_mix(int B, const c32 *W, int T, int nblocks, int nsrc, float *bus0, float *bus1, int64_t tl,
-                              const double *vol, const c32 *tables, hipStream_t s)
+                              const double *vol, float *out, int64_t out_stride, int64_t out_len, const c32 *tables,
+                              hipStream_t s)
 {
     switch (B) {
-    case 1024: return launch_inv_mix_t<1024>(W, T, nblocks, nsrc, bus0, bus1, tl, vol, tables, s);
-    case 2048: return launch_inv_mix_t<2048>(W, T, nblocks, nsrc, bus0, bus1, tl, vol, tables, s);
-    case 4096: return launch_inv_mix_t<4096>(W, T, nblocks, nsrc, bus0, bus1, tl, vol, tables, s);
-    case 8192: return launch_inv_mix_t<8192>(W, T, nblocks, nsrc, bus0, bus1, tl, vol, tables, s);
+    case 1024: return launch_inv_mix_t<1024>(W, T, nblocks, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tables, s);
+    case 2048: return launch_inv_mix_t<2048>(W, T, nblocks, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tables, s);
+    case 4096: return launch_inv_mix_t<4096>(W, T, nblocks, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tables, s);
+    case 8192: return launch_inv_mix_t<8192>(W, T, nblocks, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tables, s);
     }
     return hipErrorInvalidValue;
 }

@@ -30,7 +30,8 @@ hipError_t launch_hpack(const c32 *Zir, c32 *Hc, const c32 *wbin, int B, int P, 
 hipError_t launch_mac(int PG, const c32 *Z, c32 *W, const c32 *Hc, const c32 *wbin, const int32_t *job_irch,
                       int B, int T, int Tout, int Tin, int Pp, int njobs, int tchunk, hipStream_t s);
 hipError_t launch_fft_inv_mix(int B, const c32 *W, int T, int nblocks, int nsrc, float *bus0, float *bus1, int64_t tl,
-                              const double *vol, const c32 *tables, hipStream_t s);
+                              const double *vol, float *out, int64_t out_stride, int64_t out_len, const c32 *tables,
+                              hipStream_t s);
 
 size_t mix_scratch_bytes(int64_t nsrc);  // bytes of device scratch launch_mix needs
 hipError_t launch_mix(float *t0, float *t1, int tch, int64_t tl, const wp_src *srcs_dev, void *scratch,

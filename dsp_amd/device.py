@@ -91,6 +91,19 @@ class BatchedConvolver:
                                                   int(target[0].shape[0]), g, _stream_ptr(torch)), "wp_conv_mix_run_dev")
         return target
 
+    def run_and_mix(self, x, out, target, vol, in_len=None):
+        """go() results for every job into `out` AND the master bus into `target`, one pass."""
+        import torch
+        assert x.is_cuda and out.is_cuda and x.shape[0] == self.njobs and out.shape[0] == self.njobs
+        assert out.shape[1] >= self.out_len and x.stride(1) == 1 and out.stride(1) == 1
+        n = int(x.shape[1]) if in_len is None else int(in_len)
+        tp = (C.c_void_p * 2)(target[0].data_ptr(), target[1].data_ptr())
+        g = (C.c_double * (self.njobs // 2))(*[float(v) for v in vol])
+        capi.check(capi.lib().wp_conv_run_mix_dev(self.handle, C.c_void_p(x.data_ptr()), x.stride(0), n,
+                                                  C.c_void_p(out.data_ptr()), out.stride(0), tp, int(target[0].shape[0]), g,
+                                                  _stream_ptr(torch)), "wp_conv_run_mix_dev")
+        return out, target
+
     def profile(self, enable=True):
         capi.check(capi.lib().wp_conv_profile(self.handle, 1 if enable else 0), "wp_conv_profile")
 

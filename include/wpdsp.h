@@ -92,6 +92,12 @@ int wp_conv_run_dev(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t 
  * host array of njobs/2 gains. */
 int wp_conv_mix_run_dev(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len, float *const *tgt_dev,
                         int64_t tl, const double *vol, void *stream);
+/* The same in one pass WITH the per-track results: out_dev receives every job's
+ * L+M samples exactly as wp_conv_run_dev writes them, and the bus is folded from
+ * those samples inside the same kernel (the results are not read back).  Equals
+ * wp_conv_run_dev followed by wp_mix_dev, bit for bit, on both outputs. */
+int wp_conv_run_mix_dev(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len, float *out_dev,
+                        int64_t out_stride, float *const *tgt_dev, int64_t tl, const double *vol, void *stream);
 /* Device bytes of workspace a wp_conv holds. */
 int64_t wp_conv_workspace_bytes(const wp_conv *c);
 /* Measurement hook (no reference counterpart): when enabled, wp_conv_run_dev

@@ -173,3 +173,13 @@ def test_fused_reverb_mix_is_bit_identical_to_unfused(torch, L, M, tracks, tl):
     conv.run_mix(x, [bus_b[0], bus_b[1]], vol)
     torch.cuda.synchronize()
     assert torch.equal(bus_a.view(torch.int32), bus_b.view(torch.int32))
+    # one-pass variant that also writes the per-track results: both outputs identical
+    bus_c = bus_a.clone()
+    device.synth_noise(bus_c[0], 9)
+    device.synth_noise(bus_c[1], 10)
+    out_c = torch.full_like(out, 3.0)
+    conv.run_and_mix(x, out_c, [bus_c[0], bus_c[1]], vol)
+    torch.cuda.synchronize()
+    assert torch.equal(bus_a.view(torch.int32), bus_c.view(torch.int32))
+    assert torch.equal(out[:, :L + M].view(torch.int32), out_c[:, :L + M].view(torch.int32))
+    assert (out_c[:, L + M:] == 3.0).all()
