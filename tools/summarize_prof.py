@@ -15,7 +15,7 @@ def short(name):
     for k in ("k_fft_fwd", "k_fft_inv", "k_mac", "k_mix_prep", "k_mix", "k_hpack", "k_synth_noise"):
         if k in n:
             t = n[n.index(k):]
-            return t[:40]
+            return t[:44]
     return n[:40]
 
 
@@ -48,7 +48,9 @@ import json
 traffic = {}
 for k in acc:
     base = k.split("<")[0]
-    if base in ("k_fft_fwd", "k_mac", "k_fft_inv", "k_fft_inv_mix", "k_mix") and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
+    if base == "k_fft_inv_mix":
+        base = "k_fft_inv_mix_w" if "true" in k else "k_fft_inv_mix"
+    if base in ("k_fft_fwd", "k_mac", "k_fft_inv", "k_fft_inv_mix", "k_fft_inv_mix_w", "k_mix") and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
         f = acc[k]["FETCH_SIZE"][0] / acc[k]["FETCH_SIZE"][1]
         w = acc[k]["WRITE_SIZE"][0] / acc[k]["WRITE_SIZE"][1]
         if base == "k_fft_fwd" and f < 1e5:
