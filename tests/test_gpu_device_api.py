@@ -23,14 +23,29 @@ def torch():
     return torch
 
 
-def test_node_shims_parity_on_gpu():
+def _node():
     node = shutil.which("node")
     if not node:
         pytest.skip("node is not installed on this box")
-    out = subprocess.run([node, "--no-warnings", os.path.join(ROOT, "tests", "node", "test_shims.mjs")],
+    if not os.path.exists(os.path.join(ROOT, "dsp_amd", "napi", "wpdsp.node")):
+        pytest.skip("the N-API addon is not built (make -C dsp_amd/napi)")
+    return node
+
+
+def test_node_shims_parity_on_gpu():
+    out = subprocess.run([_node(), "--no-warnings", os.path.join(ROOT, "tests", "node", "test_shims.mjs")],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.strip().startswith("ok "), out.stdout
+
+
+def test_node_addon_in_worker_threads():
+    """Context-aware addon: two worker_threads use the shims concurrently with a kernel
+    object cloned from the main thread; results equal the main thread's bit for bit."""
+    out = subprocess.run([_node(), "--no-warnings", os.path.join(ROOT, "tests", "node", "test_workers.mjs")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "ok workers 2" in out.stdout, out.stdout
 
 
 def test_synth_noise_device_matches_oracle(torch, oracle):
@@ -183,3 +198,56 @@ def test_fused_reverb_mix_is_bit_identical_to_unfused(torch, L, M, tracks, tl):
     assert torch.equal(bus_a.view(torch.int32), bus_c.view(torch.int32))
     assert torch.equal(out[:, :L + M].view(torch.int32), out_c[:, :L + M].view(torch.int32))
     assert (out_c[:, L + M:] == 3.0).all()
+
+
+def test_reverb_tail_roundtrip_and_error_paths(torch, oracle):
+    from dsp_amd import capi, convolve, mix
+    lib = capi.lib()
+    L, M = 500, 300
+    ir = convolve.IR([oracle.synth_ir(M, 5), oracle.synth_ir(M, 6)], L)
+    job_ch = (C.c_int32 * 2)(0, 1)
+    rv = capi.check_handle(lib.wp_reverb_create(ir.handle, 2, job_ch, 10), "wp_reverb_create")
+    try:
+        xs = [oracle.synth_noise(L, 1), oracle.synth_noise(L, 2)]
+        outs = [np.empty(L + M, np.float32), np.empty(L + M, np.float32)]
+        ip = (capi.f32p * 2)(*[a.ctypes.data_as(capi.f32p) for a in xs])
+        op = (capi.f32p * 2)(*[a.ctypes.data_as(capi.f32p) for a in outs])
+        v = capi.WpReverbView()
+        capi.check(lib.wp_reverb_block(rv, ip, L, op, C.byref(v)))
+        # the tail the library carries is the view the reference would store (impulse-reverb-stereo.js:23-25)
+        assert lib.wp_reverb_tail_len(rv) == v.prev_len == M - 10
+        tails = [np.empty(v.prev_len, np.float32), np.empty(v.prev_len, np.float32)]
+        tp = (capi.f32p * 2)(*[a.ctypes.data_as(capi.f32p) for a in tails])
+        capi.check(lib.wp_reverb_get_tail(rv, tp))
+        for ch in range(2):
+            assert np.array_equal(tails[ch], outs[ch][v.prev_off:v.prev_off + v.prev_len])
+        # set_tail then one block == adding that tail to a plain convolution
+        capi.check(lib.wp_reverb_set_tail(rv, tp, v.prev_len))
+        capi.check(lib.wp_reverb_block(rv, ip, L, op, C.byref(v)))
+        for ch in range(2):
+            plain = np.empty(L + M, np.float32)
+            capi.check(lib.wp_convolve(ir.handle, ch, xs[ch].ctypes.data_as(capi.f32p), L, plain.ctypes.data_as(capi.f32p)))
+            want = plain.copy()
+            want[:len(tails[ch])] += tails[ch]
+            assert np.array_equal(outs[ch], want)
+    finally:
+        lib.wp_reverb_destroy(rv)
+    # an input longer than L is fine while the reference's FFT would not wrap ...
+    k = convolve.fft_process_kernel(600, oracle.synth_ir(200, 7))     # N = 1024
+    go = convolve.fft_convolution(600, k, 200)
+    x = oracle.synth_noise(800, 3)
+    want = oracle.fft_convolution(600, oracle.fft_process_kernel(600, oracle.synth_ir(200, 7)), 200)(x)
+    assert float(np.abs(go(x).astype(np.float64) - want).max()) <= TOL
+    with pytest.raises(NotImplementedError):                          # ... 1000 + 200 - 1 > 1024 wraps: refused, not mis-computed
+        go(oracle.synth_noise(1000, 3))
+    with pytest.raises(IndexError):
+        go(oracle.synth_noise(1025, 3))
+    bad = (C.c_int32 * 1)(2)
+    assert not lib.wp_conv_create(ir.handle, 1, bad) and "IR channel" in capi.last_error()
+    # layouts the reference ignores stay untouched (mix-buffers.js:18-44, 47-69)
+    t3 = [np.ones(8, np.float32) for _ in range(3)]
+    mix.mix_buffers(t3, [np.ones(8, np.float32)])
+    assert all((t == 1).all() for t in t3)
+    t2 = [np.ones(8, np.float32), np.ones(8, np.float32)]
+    mix.mix_buffers(t2, [np.ones(8, np.float32)] * 3)
+    assert all((t == 1).all() for t in t2)
