@@ -782,15 +782,30 @@ extern "C" int wp_mix(float *const *tgt, int tch, int64_t tl, const wp_src *srcs
         }
         if (S.vol_vec) place(S.vol_vec, sizeof(double) * (size_t)tl);
     }
-    char *d = nullptr;
-    HIPCHK(hipMalloc((void **)&d, total > 0 ? total : 256));
+    // grow-only staging area, one per calling thread: repeated mixBuffers calls (one per bar in
+    // the reference's render loop) do not pay for hipMalloc/hipFree each time
+    static thread_local struct Stage {
+        char *p = nullptr;
+        size_t cap = 0;
+        int dev = -1;  // released with the process (no destructor: the HIP runtime may already be gone)
+    } stage;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (stage.cap < total || stage.dev != dev) {
+        if (stage.p) (void)hipFree(stage.p);
+        stage.p = nullptr;
+        stage.cap = 0;
+        const size_t cap = total < (1 << 20) ? (1 << 20) : total + total / 4;
+        HIPCHK(hipMalloc((void **)&stage.p, cap));
+        stage.cap = cap;
+        stage.dev = dev;
+    }
+    char *d = stage.p;
     int rc = WP_OK;
-    auto cleanup = [&]() { (void)hipFree(d); };
     for (auto &kv : where) {
         if (kv.first.second == 0) continue;
         hipError_t e = hipMemcpy(d + kv.second, kv.first.first, kv.first.second, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
-            cleanup();
             return fail(WP_ERR_HIP, "hipMemcpy(H2D) failed: %s", hipGetErrorString(e));
         }
     }
@@ -813,6 +828,5 @@ extern "C" int wp_mix(float *const *tgt, int tch, int64_t tl, const wp_src *srcs
             if (e != hipSuccess) rc = fail(WP_ERR_HIP, "hipMemcpy(D2H) failed: %s", hipGetErrorString(e));
         }
     }
-    cleanup();
     return rc;
 }
