@@ -251,3 +251,38 @@ def test_reverb_tail_roundtrip_and_error_paths(torch, oracle):
     t2 = [np.ones(8, np.float32), np.ones(8, np.float32)]
     mix.mix_buffers(t2, [np.ones(8, np.float32)] * 3)
     assert all((t == 1).all() for t in t2)
+
+
+def test_bench_path_full_length_against_reference_golden(torch):
+    """The benchmark's own call sequence (device-resident noise, batched jobs, one-pass
+    results + bus) at the full 60 s x 2 s-IR job size: job 0 is the (seed 1000, IR seed
+    500000) channel-job whose output the reference JavaScript produced for the fixtures."""
+    from conftest import from_bits, load_golden
+    from dsp_amd import device
+    g = load_golden("g5_config_sized.json")["c3_job0"]
+    F, M, tracks = g["L"], g["M"], 4
+    njobs = 2 * tracks
+    irs = torch.from_numpy(np.stack([device.synth_ir(M, 500000), device.synth_ir(M, 500001)])).cuda()
+    ir = device.DeviceIR(irs, F)
+    conv = device.BatchedConvolver(ir, [j % 2 for j in range(njobs)])
+    x = torch.empty((njobs, F), dtype=torch.float32, device="cuda")
+    for j in range(njobs):
+        device.synth_noise(x[j], 1000 + j)
+    out = torch.empty((njobs, F + M), dtype=torch.float32, device="cuda")
+    bus = torch.zeros((2, F), dtype=torch.float32, device="cuda")
+    vol = [1.0 / 256] * tracks
+    conv.run_and_mix(x, out, [bus[0], bus[1]], vol)
+    y0 = out[0].cpu().numpy()
+    want = from_bits(g["samples"])
+    err = float(np.abs(y0[::g["stride"]].astype(np.float64) - want).max())
+    assert err <= TOL, err
+    assert float(np.abs(y0[:64].astype(np.float64) - from_bits(g["head"])).max()) <= TOL
+    assert float(np.abs(y0[-64:].astype(np.float64) - from_bits(g["tail"])).max()) <= TOL
+    # the bus is the in-order f64 fold of the written results (checked on the host for a slice)
+    o = out[:, :F].cpu().numpy()
+    sl = slice(1234567, 1234567 + 4096)
+    for ch in range(2):
+        acc = np.zeros(4096, np.float32)
+        for t in range(tracks):
+            acc = (acc.astype(np.float64) + o[2 * t + ch, sl].astype(np.float64) * vol[t]).astype(np.float32)
+        assert np.array_equal(acc, bus[ch, sl].cpu().numpy())
