@@ -5,6 +5,14 @@ import sys
 import numpy as np
 import pytest
 
+# torch bundles its own HIP runtime; load it before libwpdsp.so pulls in the system one, so a
+# process that uses both (device-API tests, bench.py) ends up with a single runtime whatever
+# order the test modules run in.
+try:
+    import torch  # noqa: F401
+except Exception:  # torch is optional for the oracle / boundary tests
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
