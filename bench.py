@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — whole-job throughput of the reverb+mix hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the one the metric's target is quoted on):
+Workload (the batched-reverb configuration the headline metric is quoted on):
 256 independent stereo tracks x 60 s at 48 kHz (F = 2 880 000 frames), each
 channel convolved with a 2 s IR (M = 96 000; one `go` of L = F per channel-job,
 lib/convolve.js:570-583), then all 256 stereo results summed into one stereo
@@ -210,7 +210,7 @@ def main():
         # blocks each kernel touches: the fused path only needs the blocks that reach the bus (tl = F)
         Tout = (F + B - 1) // B if fused else T
         Tin = min(Tout, (F + B - 1) // B + 1)
-        # algorithmic bytes per launch (see DESIGN.md "Kernels and rooflines")
+        # algorithmic bytes per launch: every operand of the kernel read or written exactly once
         alg = {
             "k_fft_fwd": njobs * (4 * F + 8 * B * Tin),
             "k_mac": njobs * (8 * B * Tin + 8 * B * Tout),

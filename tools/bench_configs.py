@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Secondary measurements for the other BASELINE.json configurations (the one
+"""Secondary measurements for the other benchmark configurations (the one
 JSON line of bench.py stays on the 256-track workload).  Run on the GPU box:
 
     python tools/bench_configs.py [c2] [c4] [c5]
