@@ -42,6 +42,7 @@ PROTOTYPES = {
     "wp_ir_destroy": (None, [C.c_void_p]),
     "wp_ir_info": (C.c_int64, [C.c_void_p, C.c_int]),
     "wp_convolve": (C.c_int, [C.c_void_p, C.c_int, f32p, C.c_int64, f32p]),
+    "wp_convolve_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "wp_conv_create": (C.c_void_p, [C.c_void_p, C.c_int, i32p]),
     "wp_conv_destroy": (None, [C.c_void_p]),
     "wp_conv_run_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
@@ -60,12 +61,25 @@ PROTOTYPES = {
     "wp_reverb_block": (C.c_int, [C.c_void_p, C.POINTER(f32p), C.c_int64, C.POINTER(f32p), C.POINTER(WpReverbView)]),
     "wp_reverb_block_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), i64p,
                                       C.POINTER(WpReverbView), C.c_void_p]),
+    "wp_reverb_block_to": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                     C.POINTER(WpReverbView), C.c_void_p]),
     "wp_reverb_set_tail": (C.c_int, [C.c_void_p, C.POINTER(f32p), C.c_int64]),
+    "wp_reverb_set_tail_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
     "wp_reverb_tail_len": (C.c_int64, [C.c_void_p]),
     "wp_reverb_get_tail": (C.c_int, [C.c_void_p, C.POINTER(f32p)]),
     "wp_mix_sl": (C.c_int32, [C.c_int64, C.c_double]),
     "wp_mix": (C.c_int, [C.POINTER(f32p), C.c_int, C.c_int64, C.POINTER(WpSrc), C.c_int64]),
     "wp_mix_dev": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "wp_buf_create": (C.c_void_p, [C.c_int, C.c_int64]),
+    "wp_buf_id": (C.c_uint64, [C.c_void_p]),
+    "wp_buf_open": (C.c_void_p, [C.c_uint64]),
+    "wp_buf_release": (None, [C.c_void_p]),
+    "wp_buf_info": (C.c_int64, [C.c_void_p, C.c_int]),
+    "wp_buf_channel": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "wp_buf_write": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, f32p, C.c_int64]),
+    "wp_buf_read": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, f32p, C.c_int64]),
+    "wp_buf_copy": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    "wp_buf_fill": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_float, C.c_void_p]),
     "wp_ring_pos": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "wp_ring_advance": (C.c_int64, [C.c_int64, C.c_int64]),
     "wp_beat_rate": (C.c_int64, [C.c_double, C.c_double]),

@@ -213,7 +213,8 @@ struct wp_ir {
     c32 *Hp;           // [nch][Pp][B] per-bin partition spectra
     const c32 *tables;
     int64_t bytes;
-    wp_conv *single;   // lazily built 1-job plan for wp_convolve
+    wp_conv *single;   // lazily built 1-job plan for wp_convolve / wp_convolve_dev
+    int single_ch;     // IR channel that plan currently names
     float *stage_in, *stage_out;
 };
 
@@ -237,8 +238,10 @@ struct wp_reverb {
     int64_t offset;
     int64_t stride;     // floats between jobs in buf[]
     float *buf[2];      // ping-pong curr buffers, njobs*stride each
-    int cur;            // buffer holding the latest curr (and the prev view)
-    int64_t prev_off, prev_len;
+    int cur;            // ping-pong buffer written last by wp_reverb_block_dev
+    const float *prev;  // carried tail of job 0 (job j at prev + j*prev_stride): inside buf[] or a caller's buffer
+    int64_t prev_stride;
+    int64_t prev_off, prev_len;  // the tail as a view of the latest curr: curr[prev_off, prev_off+prev_len)
     float *stage_in;    // host-API staging, njobs*in_stride
     int64_t stage_in_len;
 };
@@ -284,6 +287,7 @@ static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, 
     ir->PG = choose_PG(ir->P);
     ir->Pp = ((ir->P + ir->PG - 1) / ir->PG) * ir->PG;
     ir->single = nullptr;
+    ir->single_ch = 0;
     ir->stage_in = ir->stage_out = nullptr;
     ir->Hp = nullptr;
     c32 *Zir = nullptr;
@@ -574,6 +578,31 @@ extern "C" int wp_conv_run_mix_dev(wp_conv *c, const float *in_dev, int64_t in_s
                            "wp_conv_run_mix_dev");
 }
 
+static int single_plan(wp_ir *ir, int ch)
+{
+    if (!ir->single) {
+        const int32_t zero = 0;
+        ir->single = wp_conv_create(ir, 1, &zero);
+        if (!ir->single) return WP_ERR_HIP;
+        ir->single_ch = 0;
+    }
+    if (ir->single_ch != ch) {
+        HIPCHK(hipMemcpy(ir->single->job_irch, &ch, sizeof(int32_t), hipMemcpyHostToDevice));
+        ir->single_ch = ch;
+    }
+    return WP_OK;
+}
+
+extern "C" int wp_convolve_dev(wp_ir *ir, int ch, const float *in_dev, int64_t in_len, float *out_dev, void *stream)
+{
+    if (int rc = need_device()) return rc;
+    if (!ir || !out_dev || (!in_dev && in_len > 0)) return fail(WP_ERR_INVALID, "wp_convolve_dev: null argument");
+    if (ch < 0 || ch >= ir->nch) return fail(WP_ERR_INVALID, "wp_convolve_dev: IR channel %d of %d", ch, ir->nch);
+    if (int rc = check_in_len(ir, in_len)) return rc;
+    if (int rc = single_plan(ir, ch)) return rc;
+    return wp_conv_run_dev(ir->single, in_dev, 0, in_len, out_dev, 0, nullptr, 0, 0, stream);
+}
+
 extern "C" int wp_convolve(wp_ir *ir, int ch, const float *in, int64_t in_len, float *out)
 {
     if (int rc = need_device()) return rc;
@@ -581,16 +610,12 @@ extern "C" int wp_convolve(wp_ir *ir, int ch, const float *in, int64_t in_len, f
     if (ch < 0 || ch >= ir->nch) return fail(WP_ERR_INVALID, "wp_convolve: IR channel %d of %d", ch, ir->nch);
     if (int rc = check_in_len(ir, in_len)) return rc;
     const int64_t N = wp_next_pot((int32_t)(ir->L + ir->M));
-    if (!ir->single) {
-        const int32_t zero = 0;
-        ir->single = wp_conv_create(ir, 1, &zero);
-        if (!ir->single) return WP_ERR_HIP;
+    if (!ir->stage_in) {
         HIPCHK(hipMalloc((void **)&ir->stage_in, sizeof(float) * (size_t)(N + 2)));
         HIPCHK(hipMalloc((void **)&ir->stage_out, sizeof(float) * (size_t)(ir->L + ir->M + 2)));
     }
-    HIPCHK(hipMemcpy(ir->single->job_irch, &ch, sizeof(int32_t), hipMemcpyHostToDevice));
     if (in_len > 0) HIPCHK(hipMemcpy(ir->stage_in, in, sizeof(float) * (size_t)in_len, hipMemcpyHostToDevice));
-    if (int rc = wp_conv_run_dev(ir->single, ir->stage_in, 0, in_len, ir->stage_out, 0, nullptr, 0, 0, nullptr)) return rc;
+    if (int rc = wp_convolve_dev(ir, ch, ir->stage_in, in_len, ir->stage_out, nullptr)) return rc;
     HIPCHK(hipMemcpy(out, ir->stage_out, sizeof(float) * (size_t)(ir->L + ir->M), hipMemcpyDeviceToHost));
     return WP_OK;
 }
@@ -608,6 +633,8 @@ extern "C" wp_reverb *wp_reverb_create(wp_ir *ir, int njobs, const int32_t *job_
     r->stride = (ir->L + ir->M + 3) & ~(int64_t)3;
     r->buf[0] = r->buf[1] = nullptr;
     r->cur = 0;
+    r->prev = nullptr;
+    r->prev_stride = 0;
     r->prev_off = r->prev_len = 0;
     r->stage_in = nullptr;
     r->stage_in_len = 0;
@@ -632,21 +659,34 @@ extern "C" void wp_reverb_destroy(wp_reverb *r)
     delete r;
 }
 
+extern "C" int wp_reverb_block_to(wp_reverb *r, const float *in_dev, int64_t in_stride, int64_t in_len,
+                                  float *curr_dev, int64_t curr_stride, wp_reverb_view *v, void *stream)
+{
+    if (int rc = need_device()) return rc;
+    if (!r || !v || !curr_dev) return fail(WP_ERR_INVALID, "wp_reverb_block_to: null argument");
+    const wp_ir *ir = r->conv->ir;
+    if (r->njobs > 1 && curr_stride < ir->L + ir->M) return fail(WP_ERR_INVALID, "wp_reverb_block_to: jobs would overlap in the result buffer");
+    if (int rc = wp_conv_run_dev(r->conv, in_dev, in_stride, in_len, curr_dev, curr_stride,
+                                 r->prev_len > 0 ? r->prev : nullptr, r->prev_stride, r->prev_len, stream))
+        return rc;
+    wp_reverb_view_for(ir->L, ir->M, r->offset, in_len, v);
+    r->prev = curr_dev + v->prev_off;
+    r->prev_stride = curr_stride;
+    r->prev_off = v->prev_off;
+    r->prev_len = v->prev_len;
+    return WP_OK;
+}
+
 extern "C" int wp_reverb_block_dev(wp_reverb *r, const float *in_dev, int64_t in_stride, int64_t in_len,
                                    float **curr_dev, int64_t *curr_stride, wp_reverb_view *v, void *stream)
 {
     if (int rc = need_device()) return rc;
     if (!r || !v) return fail(WP_ERR_INVALID, "wp_reverb_block_dev: null argument");
-    const wp_ir *ir = r->conv->ir;
     const int nxt = r->cur ^ 1;
-    const float *prev = r->prev_len > 0 ? r->buf[r->cur] + r->prev_off : nullptr;
-    if (int rc = wp_conv_run_dev(r->conv, in_dev, in_stride, in_len, r->buf[nxt], r->stride, prev, r->stride,
-                                 r->prev_len, stream))
-        return rc;
-    wp_reverb_view_for(ir->L, ir->M, r->offset, in_len, v);
+    if (r->prev_len > 0 && r->prev >= r->buf[nxt] && r->prev < r->buf[nxt] + (size_t)r->njobs * r->stride)
+        return fail(WP_ERR_INVALID, "wp_reverb_block_dev: carried tail lives in the buffer about to be overwritten");
+    if (int rc = wp_reverb_block_to(r, in_dev, in_stride, in_len, r->buf[nxt], r->stride, v, stream)) return rc;
     r->cur = nxt;
-    r->prev_off = v->prev_off;
-    r->prev_len = v->prev_len;
     if (curr_dev) *curr_dev = r->buf[nxt];
     if (curr_stride) *curr_stride = r->stride;
     return WP_OK;
@@ -687,6 +727,22 @@ extern "C" int wp_reverb_set_tail(wp_reverb *r, const float *const *prev, int64_
     if (prev_len > ir->L + ir->M) prev_len = ir->L + ir->M;  // adds past curr.length are no-ops on a typed array
     for (int j = 0; j < r->njobs && prev_len > 0; j++)
         HIPCHK(hipMemcpy(r->buf[r->cur] + (size_t)j * r->stride, prev[j], sizeof(float) * (size_t)prev_len, hipMemcpyHostToDevice));
+    r->prev = r->buf[r->cur];
+    r->prev_stride = r->stride;
+    r->prev_off = 0;
+    r->prev_len = prev_len;
+    return WP_OK;
+}
+
+extern "C" int wp_reverb_set_tail_dev(wp_reverb *r, const float *prev_dev, int64_t prev_stride, int64_t prev_len)
+{
+    if (int rc = need_device()) return rc;
+    if (!r || (prev_len > 0 && !prev_dev)) return fail(WP_ERR_INVALID, "wp_reverb_set_tail_dev: null argument");
+    const wp_ir *ir = r->conv->ir;
+    if (prev_len < 0) prev_len = 0;
+    if (prev_len > ir->L + ir->M) prev_len = ir->L + ir->M;
+    r->prev = prev_dev;
+    r->prev_stride = prev_stride;
     r->prev_off = 0;
     r->prev_len = prev_len;
     return WP_OK;
@@ -699,22 +755,28 @@ extern "C" int wp_reverb_get_tail(wp_reverb *r, float *const *prev_out)
     if (int rc = need_device()) return rc;
     if (!r || !prev_out) return fail(WP_ERR_INVALID, "wp_reverb_get_tail: null argument");
     for (int j = 0; j < r->njobs && r->prev_len > 0; j++)
-        HIPCHK(hipMemcpy(prev_out[j], r->buf[r->cur] + (size_t)j * r->stride + r->prev_off, sizeof(float) * (size_t)r->prev_len, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(prev_out[j], r->prev + (size_t)j * r->prev_stride, sizeof(float) * (size_t)r->prev_len, hipMemcpyDeviceToHost));
     return WP_OK;
 }
 
 // ---------------------------------------------------------------------------
 // mix
+// Per calling thread and device: the wp_src copy + mix_desc array of the call in flight.
+// Threads never share it (worker threads mix concurrently); within a thread a call on a
+// different stream first waits for the previous call's stream, because its kernels may
+// still be reading the area.
 struct Scratch {
     void *p = nullptr;
     size_t cap = 0;
+    hipStream_t last = nullptr;
+    bool used = false;
 };
-static std::map<int, Scratch> g_mix_scratch;  // per device: wp_src copy + mix_desc array
 
 static int mix_scratch(int dev, size_t bytes, hipStream_t s, void **out)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Scratch &sc = g_mix_scratch[dev];
+    static thread_local std::map<int, Scratch> scratch;  // released with the process
+    Scratch &sc = scratch[dev];
+    if (sc.used && sc.last != s) HIPCHK(hipStreamSynchronize(sc.last));
     if (sc.cap < bytes) {
         if (sc.p) {
             HIPCHK(hipStreamSynchronize(s));
@@ -726,6 +788,8 @@ static int mix_scratch(int dev, size_t bytes, hipStream_t s, void **out)
         HIPCHK(hipMalloc(&sc.p, cap));
         sc.cap = cap;
     }
+    sc.last = s;
+    sc.used = true;
     *out = sc.p;
     return WP_OK;
 }
@@ -829,4 +893,209 @@ extern "C" int wp_mix(float *const *tgt, int tch, int64_t tl, const wp_src *srcs
         }
     }
     return rc;
+}
+
+// ---------------------------------------------------------------------------
+// device-resident sample buffers
+//
+// The reference's sample buffers are arrays of Float32Array channels over
+// SharedArrayBuffers that every worker can see (src/buffer-service.js,
+// src/mix-worker-thread.js:14-16,23-24).  A wp_buf is the same thing in HBM: nch
+// channels of `frames` floats, visible to every thread of the process through a
+// numeric id, reference-counted.  Allocations are recycled through a small
+// size-keyed pool so that a fresh result buffer per block (what go() returns in
+// the reference, lib/convolve.js:575,582) does not cost a hipMalloc per block.
+struct wp_buf {
+    uint64_t id;
+    int dev;
+    int nch;
+    int64_t frames;
+    int64_t stride;  // floats between channels (multiple of 64: every channel 256-byte aligned)
+    float *p;
+    size_t bytes;
+    int refs;
+};
+
+static std::mutex g_buf_mu;
+static std::map<uint64_t, wp_buf *> g_bufs;
+static uint64_t g_next_buf_id = 1;
+static std::multimap<std::pair<int, size_t>, void *> g_pool;  // (device, bytes) -> free allocation
+static size_t g_pool_bytes = 0;
+
+static size_t pool_limit()
+{
+    static const size_t lim = [] {
+        const char *e = getenv("WPDSP_POOL_MB");
+        const long mb = e ? atol(e) : 2048;
+        return (size_t)(mb < 0 ? 0 : mb) << 20;
+    }();
+    return lim;
+}
+
+extern "C" wp_buf *wp_buf_create(int nch, int64_t frames)
+{
+    if (need_device()) return nullptr;
+    if (nch < 1 || nch > 64 || frames < 0 || frames > ((int64_t)1 << 40)) {
+        fail(WP_ERR_INVALID, "wp_buf_create: bad shape (%d channels, %lld frames)", nch, (long long)frames);
+        return nullptr;
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        fail(WP_ERR_HIP, "hipGetDevice failed");
+        return nullptr;
+    }
+    const int64_t stride = (frames + 63) & ~(int64_t)63;
+    size_t bytes = sizeof(float) * (size_t)nch * (size_t)(stride > 0 ? stride : 64);
+    void *p = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_buf_mu);
+        auto it = g_pool.find(std::make_pair(dev, bytes));
+        if (it != g_pool.end()) {
+            p = it->second;
+            g_pool.erase(it);
+            g_pool_bytes -= bytes;
+        }
+    }
+    hipError_t e = hipSuccess;
+    if (!p) e = hipMalloc(&p, bytes);
+    // a fresh typed array is zero-filled; stream order keeps this ahead of any later use
+    if (e == hipSuccess) e = hipMemsetAsync(p, 0, bytes, nullptr);
+    if (e != hipSuccess) {
+        fail(WP_ERR_HIP, "wp_buf_create: %zu bytes: %s", bytes, hipGetErrorString(e));
+        if (p) (void)hipFree(p);
+        return nullptr;
+    }
+    wp_buf *b = new wp_buf();
+    b->dev = dev;
+    b->nch = nch;
+    b->frames = frames;
+    b->stride = stride;
+    b->p = (float *)p;
+    b->bytes = bytes;
+    b->refs = 1;
+    std::lock_guard<std::mutex> lk(g_buf_mu);
+    b->id = g_next_buf_id++;
+    g_bufs[b->id] = b;
+    return b;
+}
+
+extern "C" uint64_t wp_buf_id(const wp_buf *b) { return b ? b->id : 0; }
+
+extern "C" wp_buf *wp_buf_open(uint64_t id)
+{
+    std::lock_guard<std::mutex> lk(g_buf_mu);
+    auto it = g_bufs.find(id);
+    if (it == g_bufs.end()) {
+        fail(WP_ERR_INVALID, "wp_buf_open: no live buffer with id %llu", (unsigned long long)id);
+        return nullptr;
+    }
+    it->second->refs++;
+    return it->second;
+}
+
+extern "C" void wp_buf_release(wp_buf *b)
+{
+    if (!b) return;
+    void *to_free = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_buf_mu);
+        if (--b->refs > 0) return;
+        g_bufs.erase(b->id);
+        if (g_pool_bytes + b->bytes <= pool_limit()) {
+            g_pool.emplace(std::make_pair(b->dev, b->bytes), b->p);
+            g_pool_bytes += b->bytes;
+        } else {
+            to_free = b->p;
+        }
+    }
+    if (to_free) (void)hipFree(to_free);
+    delete b;
+}
+
+extern "C" int64_t wp_buf_info(const wp_buf *b, int which)
+{
+    if (!b) return WP_ERR_INVALID;
+    switch (which) {
+    case 0: return b->nch;
+    case 1: return b->frames;
+    case 2: return b->stride;
+    case 3: return b->dev;
+    case 4: return (int64_t)b->bytes;
+    }
+    return WP_ERR_INVALID;
+}
+
+extern "C" float *wp_buf_channel(const wp_buf *b, int ch)
+{
+    if (!b || ch < 0 || ch >= b->nch) {
+        fail(WP_ERR_INVALID, "wp_buf_channel: channel %d out of range", ch);
+        return nullptr;
+    }
+    return b->p + (size_t)ch * b->stride;
+}
+
+static int buf_span(const wp_buf *b, int ch, int64_t off, int64_t n, const char *who)
+{
+    if (!b) return fail(WP_ERR_INVALID, "%s: null buffer", who);
+    if (ch < 0 || ch >= b->nch) return fail(WP_ERR_INVALID, "%s: channel %d of %d", who, ch, b->nch);
+    // TypedArray.set throws RangeError("offset is out of bounds") for a span past the end
+    if (off < 0 || n < 0 || off + n > b->frames)
+        return fail(WP_ERR_RANGE, "offset is out of bounds: %s of [%lld, %lld) in a channel of %lld frames", who, (long long)off, (long long)(off + n), (long long)b->frames);
+    return WP_OK;
+}
+
+extern "C" int wp_buf_write(wp_buf *b, int ch, int64_t dst_off, const float *src_host, int64_t n)
+{
+    if (int rc = need_device()) return rc;
+    if (int rc = buf_span(b, ch, dst_off, n, "wp_buf_write")) return rc;
+    if (n == 0) return WP_OK;
+    if (!src_host) return fail(WP_ERR_INVALID, "wp_buf_write: null source");
+    HIPCHK(hipMemcpy(b->p + (size_t)ch * b->stride + dst_off, src_host, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+    return WP_OK;
+}
+
+extern "C" int wp_buf_read(const wp_buf *b, int ch, int64_t src_off, float *dst_host, int64_t n)
+{
+    if (int rc = need_device()) return rc;
+    if (int rc = buf_span(b, ch, src_off, n, "wp_buf_read")) return rc;
+    if (n == 0) return WP_OK;
+    if (!dst_host) return fail(WP_ERR_INVALID, "wp_buf_read: null destination");
+    HIPCHK(hipMemcpy(dst_host, b->p + (size_t)ch * b->stride + src_off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+    return WP_OK;
+}
+
+extern "C" int wp_buf_copy(wp_buf *dst, int dch, int64_t dst_off, const wp_buf *src, int sch, int64_t src_off, int64_t n,
+                           void *stream)
+{
+    if (int rc = need_device()) return rc;
+    if (int rc = buf_span(dst, dch, dst_off, n, "wp_buf_copy(dst)")) return rc;
+    if (int rc = buf_span(src, sch, src_off, n, "wp_buf_copy(src)")) return rc;
+    if (n == 0) return WP_OK;
+    float *d = dst->p + (size_t)dch * dst->stride + dst_off;
+    const float *s = src->p + (size_t)sch * src->stride + src_off;
+    if (d == s) return WP_OK;
+    if ((d < s + n) && (s < d + n)) {
+        // TypedArray.set copies as if through a temporary when the ranges overlap
+        float *tmp = nullptr;
+        HIPCHK(hipMalloc((void **)&tmp, sizeof(float) * (size_t)n));
+        hipError_t e = hipMemcpyAsync(tmp, s, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d, tmp, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+        (void)hipFree(tmp);
+        if (e != hipSuccess) return fail(WP_ERR_HIP, "wp_buf_copy: %s", hipGetErrorString(e));
+        return WP_OK;
+    }
+    HIPCHK(hipMemcpyAsync(d, s, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return WP_OK;
+}
+
+extern "C" int wp_buf_fill(wp_buf *b, int ch, int64_t off, int64_t n, float value, void *stream)
+{
+    if (int rc = need_device()) return rc;
+    if (int rc = buf_span(b, ch, off, n, "wp_buf_fill")) return rc;
+    if (n == 0) return WP_OK;
+    uint32_t bits;
+    memcpy(&bits, &value, sizeof(bits));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(b->p + (size_t)ch * b->stride + off), (int)bits, (size_t)n, (hipStream_t)stream));
+    return WP_OK;
 }

@@ -12,6 +12,7 @@
 //   u32[0] = 0x57504b31 ('WPK1')   u32[1] = M   u32[2] = L   u32[3] = 0
 //   f32[4 .. 4+M) = impulse response samples
 import native from '../native.js'
+import { DeviceBuffer, isDeviceChannel, liveChannel } from '../src/device-buffer.js'
 
 const MAGIC = 0x57504b31
 const HEADER = 4
@@ -64,6 +65,11 @@ function fftConvolution (length, fftKernel, kernelLength) {
   }
   const ir = irHandle(fftKernel)
   function go (input) {
+    if (isDeviceChannel(input)) { // input and result stay in device memory
+      const out = DeviceBuffer.alloc(1, length + kernelLength)[0]
+      native.convolveDev(ir, 0, liveChannel(input), out)
+      return out
+    }
     return native.convolve(ir, 0, input) // new Float32Array(length + kernelLength)
   }
   go.kernel = fftKernel

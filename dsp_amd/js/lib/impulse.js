@@ -10,6 +10,7 @@
 // mono tail is a fresh view per block.
 import convolve, { irHandle } from './convolve.js'
 import native from '../native.js'
+import { DeviceBuffer, isDeviceChannel, liveChannel, keepAlive } from '../src/device-buffer.js'
 
 const KEYS = {
   1: { kernel: 'kernel:', prev: 'prev:' },
@@ -38,6 +39,8 @@ async function convolvers (c, url, length, nch) {
 export const impulseConvolve = async (c, url, length) => (await convolvers(c, url, length, 1))[0]
 export const impulseConvolveStereo = (c, url, length) => convolvers(c, url, length, 2)
 
+// When c.buffer is a DeviceBuffer the block, its result, the carried tail and the
+// returned views all stay in device memory (same view shapes, same cache keys).
 async function reverb (c, params, nch) {
   const url = params.url
   const offset = params.offset === undefined ? 0 : params.offset
@@ -45,24 +48,37 @@ async function reverb (c, params, nch) {
   const id = params.id === undefined ? '' : params.id
   const gos = await convolvers(c, url, length, nch)
   // block convolution + `curr[i] += prev[i]` run on the GPU in one launch sequence
-  const state = native.reverbCreate(irHandle(...gos.map(g => g.kernel)), nch, offset)
+  const ir = irHandle(...gos.map(g => g.kernel))
+  const state = native.reverbCreate(ir, nch, offset)
+  const resultLength = native.irInfo(ir, 5) // L + M
   const prevKey = n => KEYS[nch].prev + id + url + n
   const stored = await c.get(prevKey(c.n - c.buffer[0].length))
   const empty = () => new Float32Array()
   let prev = stored || (nch === 1 ? empty() : [empty(), empty()])
-  const tailLength = nch === 1 ? prev.length : prev[0].length
-  if (tailLength) native.reverbSetTail(state, nch === 1 ? [prev] : [prev[0], prev[1]])
+  const tails = nch === 1 ? [prev] : [prev[0], prev[1]]
+  if (tails[0].length) {
+    if (isDeviceChannel(tails[0])) native.reverbSetTailDev(state, tails.map(liveChannel))
+    else native.reverbSetTail(state, tails)
+  }
+  const view = (a, off, len) => a.subarray(off, off + len)
   return c => {
-    const r = native.reverbBlock(state, c.buffer.slice(0, nch))
-    const view = (a, off, len) => a.subarray(off, off + len)
-    if (nch === 1) {
-      prev = view(r.curr[0], r.prevOff, r.prevLen)
+    let curr, r
+    if (isDeviceChannel(c.buffer[0])) {
+      curr = DeviceBuffer.alloc(nch, resultLength)
+      r = native.reverbBlockTo(state, c.buffer.slice(0, nch).map(liveChannel), curr)
     } else {
-      prev[0] = view(r.curr[0], r.prevOff, r.prevLen)
-      prev[1] = view(r.curr[1], r.prevOff, r.prevLen)
+      r = native.reverbBlock(state, c.buffer.slice(0, nch))
+      curr = r.curr
+    }
+    if (nch === 1) {
+      prev = view(curr[0], r.prevOff, r.prevLen)
+    } else {
+      prev[0] = view(curr[0], r.prevOff, r.prevLen)
+      prev[1] = view(curr[1], r.prevOff, r.prevLen)
     }
     c.set(prevKey(c.n), prev, 5000)
-    const out = r.curr.map(a => view(a, r.retOff, r.retLen))
+    if (isDeviceChannel(curr[0])) keepAlive(Array.from(curr), 5000)
+    const out = Array.from(curr, a => view(a, r.retOff, r.retLen))
     return nch === 1 ? out[0] : out
   }
 }

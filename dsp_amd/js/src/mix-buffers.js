@@ -5,6 +5,7 @@
 // the GPU mix, which applies the reference's arithmetic (f64 multiply and add,
 // f32 store, sources in order), so results are bit-identical.
 import native from '../native.js'
+import { DeviceBuffer, isDeviceChannel, liveChannel } from './device-buffer.js'
 
 const present = v => v !== undefined && v !== null
 const layoutOk = chans => chans.length === 1 || chans.length === 2
@@ -33,9 +34,25 @@ function describe (source, frames, targetOk) {
   return d
 }
 
+// channels of one source as live device channels (host arrays are uploaded: the
+// worker's copy-back, src/mix-worker-thread.js:23-24, becomes this one transfer)
+const onDevice = chans => isDeviceChannel(chans[0])
+  ? chans.map(liveChannel)
+  : Array.from(DeviceBuffer.upload(chans))
+
 export default (target, ...sources) => {
   const frames = target[0].length
   const targetOk = layoutOk(target)
-  native.mix(target, sources.map(s => describe(s, frames, targetOk)))
+  const decoded = sources.map(s => describe(s, frames, targetOk))
+  if (isDeviceChannel(target[0])) {
+    // device-resident bus: nothing crosses PCIe except host sources on their way in
+    if (targetOk) {
+      const mixable = decoded.filter(d => layoutOk(d.ch))
+      for (const d of mixable) d.ch = onDevice(d.ch)
+      native.mixDev(Array.from(target, liveChannel), mixable)
+    }
+  } else {
+    native.mix(target, decoded)
+  }
   return target
 }

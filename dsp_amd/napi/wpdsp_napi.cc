@@ -366,6 +366,313 @@ static napi_value js_mix_sl(napi_env env, napi_callback_info info)
     return num(env, wp_mix_sl(rl, len));
 }
 
+
+// ---- device-resident buffers ----------------------------------------------------
+// A device channel is described from JavaScript as { h: <buffer handle>, ch, off, length }
+// (dsp_amd/js/src/device-buffer.js); it resolves to a device pointer and a frame count.
+static void buf_finalize(napi_env, void *p, void *) { wp_buf_release((wp_buf *)p); }
+
+struct DevChan {
+    wp_buf *buf;
+    int ch;
+    int64_t off, len;
+    float *ptr;
+};
+
+static bool get_dev_chan(napi_env env, napi_value v, DevChan *out)
+{
+    napi_valuetype vt;
+    if (napi_typeof(env, v, &vt) != napi_ok || vt != napi_object) return false;
+    napi_value h, f;
+    int64_t t;
+    if (napi_get_named_property(env, v, "h", &h) != napi_ok) return false;
+    void *p = NULL;
+    if (napi_unwrap(env, h, &p) != napi_ok || !p) return false;
+    out->buf = (wp_buf *)p;
+    if (napi_get_named_property(env, v, "ch", &f) != napi_ok || !get_i64(env, f, &t)) return false;
+    out->ch = (int)t;
+    if (napi_get_named_property(env, v, "off", &f) != napi_ok || !get_i64(env, f, &out->off)) return false;
+    if (napi_get_named_property(env, v, "length", &f) != napi_ok || !get_i64(env, f, &out->len)) return false;
+    if (out->ch < 0 || out->ch >= wp_buf_info(out->buf, 0)) return false;
+    if (out->off < 0 || out->len < 0 || out->off + out->len > wp_buf_info(out->buf, 1)) return false;
+    out->ptr = wp_buf_channel(out->buf, out->ch) + out->off;
+    return true;
+}
+
+static bool collect_dev_chans(napi_env env, napi_value arr, std::vector<DevChan> *out)
+{
+    uint32_t n = 0;
+    if (napi_get_array_length(env, arr, &n) != napi_ok) return false;
+    out->resize(n);
+    for (uint32_t c = 0; c < n; c++) {
+        napi_value e;
+        if (napi_get_element(env, arr, c, &e) != napi_ok || !get_dev_chan(env, e, &(*out)[c])) return false;
+    }
+    return true;
+}
+
+// bufCreate(nch, frames) -> handle
+static napi_value js_buf_create(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    int64_t nch, frames;
+    if (!get_i64(env, argv[0], &nch) || !get_i64(env, argv[1], &frames)) return throw_wp(env, WP_ERR_INVALID);
+    wp_buf *b = wp_buf_create((int)nch, frames);
+    if (!b) return throw_wp(env, WP_ERR_HIP);
+    return wrap_ptr(env, b, buf_finalize);
+}
+
+// bufOpen(id) -> handle (another reference to a buffer created by any thread)
+static napi_value js_buf_open(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    int64_t id;
+    if (!get_i64(env, argv[0], &id) || id <= 0) return throw_wp(env, WP_ERR_INVALID);
+    wp_buf *b = wp_buf_open((uint64_t)id);
+    if (!b) return throw_wp(env, WP_ERR_HIP);
+    return wrap_ptr(env, b, buf_finalize);
+}
+
+// bufInfo(handle, which) ; which == -1: the process-wide id
+static napi_value js_buf_info(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    wp_buf *b = unwrap<wp_buf>(env, argv[0]);
+    if (!b) return NULL;
+    int64_t which;
+    if (!get_i64(env, argv[1], &which)) return throw_wp(env, WP_ERR_INVALID);
+    if (which == -1) return num(env, (double)wp_buf_id(b));
+    return num(env, (double)wp_buf_info(b, (int)which));
+}
+
+// bufWrite(handle, ch, dstOff, Float32Array)
+static napi_value js_buf_write(napi_env env, napi_callback_info info)
+{
+    ARGS(4);
+    wp_buf *b = unwrap<wp_buf>(env, argv[0]);
+    if (!b) return NULL;
+    int64_t ch, off;
+    F32View src;
+    if (!get_i64(env, argv[1], &ch) || !get_i64(env, argv[2], &off) || !get_f32(env, argv[3], &src)) {
+        napi_throw_type_error(env, NULL, "bufWrite(handle, ch, offset, Float32Array)");
+        return NULL;
+    }
+    const int rc = wp_buf_write(b, (int)ch, off, src.data, (int64_t)src.length);
+    if (rc) return throw_wp(env, rc);
+    return NULL;
+}
+
+// bufRead(handle, ch, off, n) -> Float32Array(n)
+static napi_value js_buf_read(napi_env env, napi_callback_info info)
+{
+    ARGS(4);
+    wp_buf *b = unwrap<wp_buf>(env, argv[0]);
+    if (!b) return NULL;
+    int64_t ch, off, n;
+    if (!get_i64(env, argv[1], &ch) || !get_i64(env, argv[2], &off) || !get_i64(env, argv[3], &n) || n < 0)
+        return throw_wp(env, WP_ERR_INVALID);
+    float *out = NULL;
+    napi_value ta = new_f32(env, (size_t)n, &out);
+    if (!ta) return NULL;
+    const int rc = wp_buf_read(b, (int)ch, off, out, n);
+    if (rc) return throw_wp(env, rc);
+    return ta;
+}
+
+// bufCopy(dstChan, srcChan, dstOff): dst.set(src, dstOff) between device channels
+static napi_value js_buf_copy(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    DevChan d, s;
+    int64_t doff;
+    if (!get_dev_chan(env, argv[0], &d) || !get_dev_chan(env, argv[1], &s) || !get_i64(env, argv[2], &doff)) {
+        napi_throw_type_error(env, NULL, "bufCopy(dstChannel, srcChannel, offset)");
+        return NULL;
+    }
+    if (doff < 0 || doff + s.len > d.len) {
+        napi_throw_range_error(env, NULL, "offset is out of bounds");
+        return NULL;
+    }
+    const int rc = wp_buf_copy(d.buf, d.ch, d.off + doff, s.buf, s.ch, s.off, s.len, NULL);
+    if (rc) return throw_wp(env, rc);
+    return NULL;
+}
+
+// bufFill(chan, value, start, end)
+static napi_value js_buf_fill(napi_env env, napi_callback_info info)
+{
+    ARGS(4);
+    DevChan d;
+    double value;
+    int64_t a, b;
+    if (!get_dev_chan(env, argv[0], &d) || napi_get_value_double(env, argv[1], &value) != napi_ok ||
+        !get_i64(env, argv[2], &a) || !get_i64(env, argv[3], &b) || a < 0 || b > d.len) {
+        napi_throw_type_error(env, NULL, "bufFill(channel, value, start, end)");
+        return NULL;
+    }
+    if (b > a) {
+        const int rc = wp_buf_fill(d.buf, d.ch, d.off + a, b - a, (float)value, NULL);
+        if (rc) return throw_wp(env, rc);
+    }
+    return NULL;
+}
+
+// convolveDev(ir, irChannel, inChan, outChan): go() with input and result on the device
+static napi_value js_convolve_dev(napi_env env, napi_callback_info info)
+{
+    ARGS(4);
+    wp_ir *ir = unwrap<wp_ir>(env, argv[0]);
+    if (!ir) return NULL;
+    int64_t ch;
+    DevChan in, out;
+    if (!get_i64(env, argv[1], &ch) || !get_dev_chan(env, argv[2], &in) || !get_dev_chan(env, argv[3], &out) ||
+        out.len < wp_ir_info(ir, 5)) {
+        napi_throw_type_error(env, NULL, "convolveDev(ir, ch, inChannel, outChannel[L+M])");
+        return NULL;
+    }
+    const int rc = wp_convolve_dev(ir, (int)ch, in.ptr, in.len, out.ptr, NULL);
+    if (rc) return throw_wp(env, rc);
+    return NULL;
+}
+
+// equal spacing of job pointers: job j at p[0] + j*stride
+static bool job_stride(const std::vector<DevChan> &c, int64_t *stride)
+{
+    *stride = c.size() > 1 ? (int64_t)(c[1].ptr - c[0].ptr) : 0;
+    for (size_t j = 1; j < c.size(); j++) {
+        if (c[j].len != c[0].len) return false;
+        if ((int64_t)(c[j].ptr - c[0].ptr) != *stride * (int64_t)j) return false;
+    }
+    return true;
+}
+
+// reverbBlockTo(state, [inChan per job], [outChan per job]) -> { retOff, retLen, prevOff, prevLen }
+// The result (tail already added) lands in the out channels, each L+M frames; the
+// state keeps them referenced because the carried tail is a view into them.
+static napi_value js_reverb_block_to(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    wp_reverb *r = unwrap<wp_reverb>(env, argv[0]);
+    if (!r) return NULL;
+    std::vector<DevChan> in, out;
+    int64_t is = 0, os = 0;
+    if (!collect_dev_chans(env, argv[1], &in) || !collect_dev_chans(env, argv[2], &out) || in.empty() ||
+        in.size() != out.size() || !job_stride(in, &is) || !job_stride(out, &os)) {
+        napi_throw_type_error(env, NULL, "reverbBlockTo(state, [in channels], [out channels]): channels of one buffer, equal lengths");
+        return NULL;
+    }
+    napi_value irv;
+    NAPI_CALL(env, napi_get_named_property(env, argv[0], "ir", &irv));
+    wp_ir *ir = unwrap<wp_ir>(env, irv);
+    if (!ir) return NULL;
+    if (out[0].len < wp_ir_info(ir, 5)) {
+        napi_throw_range_error(env, NULL, "reverbBlockTo: result channels need L+M frames");
+        return NULL;
+    }
+    wp_reverb_view v;
+    const int rc = wp_reverb_block_to(r, in[0].ptr, is, in[0].len, out[0].ptr, os, &v, NULL);
+    if (rc) return throw_wp(env, rc);
+    napi_set_named_property(env, argv[0], "tailOwner", argv[2]);
+    napi_value res;
+    NAPI_CALL(env, napi_create_object(env, &res));
+    napi_set_named_property(env, res, "retOff", num(env, (double)v.ret_off));
+    napi_set_named_property(env, res, "retLen", num(env, (double)v.ret_len));
+    napi_set_named_property(env, res, "prevOff", num(env, (double)v.prev_off));
+    napi_set_named_property(env, res, "prevLen", num(env, (double)v.prev_len));
+    return res;
+}
+
+// reverbSetTailDev(state, [chan per job]): carried tail taken from device channels, no copy
+static napi_value js_reverb_set_tail_dev(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    wp_reverb *r = unwrap<wp_reverb>(env, argv[0]);
+    if (!r) return NULL;
+    std::vector<DevChan> pv;
+    int64_t ps = 0;
+    if (!collect_dev_chans(env, argv[1], &pv) || pv.empty() || !job_stride(pv, &ps)) {
+        napi_throw_type_error(env, NULL, "reverbSetTailDev(state, [channels of one buffer])");
+        return NULL;
+    }
+    const int rc = wp_reverb_set_tail_dev(r, pv[0].ptr, ps, pv[0].len);
+    if (rc) return throw_wp(env, rc);
+    napi_set_named_property(env, argv[0], "tailOwner", argv[1]);
+    return NULL;
+}
+
+// mixDev(target: [chan...], sources: [{ch:[chan...], sl, vol, volVec?, o}]) -- everything on the device
+static napi_value js_mix_dev(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    std::vector<DevChan> tgt;
+    if (!collect_dev_chans(env, argv[0], &tgt) || tgt.empty()) {
+        napi_throw_type_error(env, NULL, "mixDev: target must be an array of device channels");
+        return NULL;
+    }
+    const int64_t tl = tgt[0].len;
+    uint32_t nsrc = 0;
+    NAPI_CALL(env, napi_get_array_length(env, argv[1], &nsrc));
+    std::vector<wp_src> srcs(nsrc);
+    std::vector<wp_buf *> temps;  // gain vectors staged on the device for this call
+    auto drop_temps = [&]() {
+        for (wp_buf *t : temps) wp_buf_release(t);
+    };
+    for (uint32_t i = 0; i < nsrc; i++) {
+        napi_value s, v;
+        NAPI_CALL(env, napi_get_element(env, argv[1], i, &s));
+        wp_src &d = srcs[i];
+        memset(&d, 0, sizeof(d));
+        std::vector<DevChan> ch;
+        if (napi_get_named_property(env, s, "ch", &v) != napi_ok || !collect_dev_chans(env, v, &ch)) {
+            drop_temps();
+            napi_throw_type_error(env, NULL, "mixDev: source channels must be device channels");
+            return NULL;
+        }
+        d.nch = (int32_t)ch.size();
+        for (size_t c = 0; c < ch.size() && c < 2; c++) d.ch[c] = ch[c].ptr;
+        d.rl = ch.empty() ? 0 : ch[0].len;
+        int64_t t;
+        double f;
+        if (napi_get_named_property(env, s, "sl", &v) != napi_ok || !get_i64(env, v, &t)) { drop_temps(); return throw_wp(env, WP_ERR_INVALID); }
+        d.sl = t;
+        if (napi_get_named_property(env, s, "o", &v) != napi_ok || !get_i64(env, v, &t)) { drop_temps(); return throw_wp(env, WP_ERR_INVALID); }
+        d.o = t;
+        if (napi_get_named_property(env, s, "vol", &v) != napi_ok || napi_get_value_double(env, v, &f) != napi_ok) { drop_temps(); return throw_wp(env, WP_ERR_INVALID); }
+        d.vol = f;
+        bool has = false;
+        napi_has_named_property(env, s, "volVec", &has);
+        if (has) {
+            napi_get_named_property(env, s, "volVec", &v);
+            napi_valuetype vt;
+            napi_typeof(env, v, &vt);
+            if (vt != napi_undefined && vt != napi_null) {
+                double *vec = NULL;
+                size_t vl = 0;
+                if (!get_f64(env, v, &vec, &vl) || (int64_t)vl < tl) {
+                    drop_temps();
+                    napi_throw_type_error(env, NULL, "mixDev: volVec must be a Float64Array of the target length");
+                    return NULL;
+                }
+                // tl doubles travel as 2*tl floats' worth of bytes
+                wp_buf *t2 = wp_buf_create(1, 2 * tl);
+                if (!t2 || wp_buf_write(t2, 0, 0, (const float *)vec, 2 * tl)) {
+                    if (t2) wp_buf_release(t2);
+                    drop_temps();
+                    return throw_wp(env, WP_ERR_HIP);
+                }
+                temps.push_back(t2);
+                d.vol_vec = (const double *)wp_buf_channel(t2, 0);
+            }
+        }
+    }
+    float *tp[2] = {tgt[0].ptr, tgt.size() > 1 ? tgt[1].ptr : NULL};
+    int rc = WP_OK;
+    if (tgt.size() <= 2) rc = wp_mix_dev(tp, (int)tgt.size(), tl, srcs.data(), (int64_t)nsrc, 0, NULL);
+    drop_temps();  // recycled memory is only reused in stream order, after the mix kernel
+    if (rc) return throw_wp(env, rc);
+    return argv[0];
+}
+
 static napi_value js_ring_pos(napi_env env, napi_callback_info info)
 {
     ARGS(3);
@@ -396,6 +703,17 @@ NAPI_MODULE_INIT()
         {"reverbSetTail", NULL, js_reverb_set_tail, NULL, NULL, NULL, napi_enumerable, NULL},
         {"mix", NULL, js_mix, NULL, NULL, NULL, napi_enumerable, NULL},
         {"mixSl", NULL, js_mix_sl, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"bufCreate", NULL, js_buf_create, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"bufOpen", NULL, js_buf_open, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"bufInfo", NULL, js_buf_info, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"bufWrite", NULL, js_buf_write, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"bufRead", NULL, js_buf_read, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"bufCopy", NULL, js_buf_copy, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"bufFill", NULL, js_buf_fill, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"convolveDev", NULL, js_convolve_dev, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"reverbBlockTo", NULL, js_reverb_block_to, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"reverbSetTailDev", NULL, js_reverb_set_tail_dev, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"mixDev", NULL, js_mix_dev, NULL, NULL, NULL, napi_enumerable, NULL},
         {"ringPos", NULL, js_ring_pos, NULL, NULL, NULL, napi_enumerable, NULL},
         {"beatRate", NULL, js_beat_rate, NULL, NULL, NULL, napi_enumerable, NULL},
     };

@@ -41,6 +41,7 @@ extern "C" {
 typedef struct wp_ir wp_ir;         /* device-resident partitioned spectra of an impulse response */
 typedef struct wp_conv wp_conv;     /* a batch of channel-jobs convolving with one wp_ir */
 typedef struct wp_reverb wp_reverb; /* wp_conv + carried tail per job (block reverb) */
+typedef struct wp_buf wp_buf;       /* device-resident sample buffer: channels x frames of f32 */
 
 /* Number of visible HIP devices, or WP_ERR_NO_DEVICE.  Idempotent, thread-safe. */
 int wp_init(void);
@@ -72,6 +73,8 @@ int64_t wp_ir_info(const wp_ir *ir, int which);
 /* One go(input): ch picks the IR channel; in_len <= reference FFT length, else
  * WP_ERR_RANGE; out receives exactly L+M floats. */
 int wp_convolve(wp_ir *ir, int ch, const float *in, int64_t in_len, float *out);
+/* The same with input and result in device memory (in_len floats in, L+M out). */
+int wp_convolve_dev(wp_ir *ir, int ch, const float *in_dev, int64_t in_len, float *out_dev, void *stream);
 
 /* Batched: njobs independent go() calls sharing one launch sequence.  job_ch[j]
  * (host array) is the IR channel job j uses. */
@@ -138,9 +141,19 @@ int wp_reverb_block(wp_reverb *r, const float *const *in, int64_t in_len, float 
  * next-but-one block. */
 int wp_reverb_block_dev(wp_reverb *r, const float *in_dev, int64_t in_stride, int64_t in_len, float **curr_dev,
                         int64_t *curr_stride, wp_reverb_view *v, void *stream);
+/* Same, but curr goes into the caller's buffer (job j at curr_dev + j*curr_stride,
+ * L+M floats each) -- the counterpart of go() returning a fresh array per block
+ * (lib/impulse-reverb.js:12).  The carried tail is then a view INTO that buffer
+ * (prev = curr.subarray(-tail), :18): the caller keeps it alive and unmodified
+ * until the next block has run. */
+int wp_reverb_block_to(wp_reverb *r, const float *in_dev, int64_t in_stride, int64_t in_len, float *curr_dev,
+                       int64_t curr_stride, wp_reverb_view *v, void *stream);
 /* Carried tail in/out (the value lib/impulse-reverb.js:6,19 keeps under
  * 'prev:'+id+url+n): prev[j] has prev_len samples. */
 int wp_reverb_set_tail(wp_reverb *r, const float *const *prev, int64_t prev_len);
+/* Tail taken from device memory without a copy (job j at prev_dev + j*prev_stride);
+ * the caller keeps it alive until the next block has run. */
+int wp_reverb_set_tail_dev(wp_reverb *r, const float *prev_dev, int64_t prev_stride, int64_t prev_len);
 int64_t wp_reverb_tail_len(const wp_reverb *r);
 int wp_reverb_get_tail(wp_reverb *r, float *const *prev_out);
 
@@ -166,6 +179,36 @@ int wp_mix(float *const *tgt, int tch, int64_t tl, const wp_src *srcs, int64_t n
  * srcs array itself is in host memory unless srcs_on_device != 0. */
 int wp_mix_dev(float *const *tgt_dev, int tch, int64_t tl, const wp_src *srcs, int64_t nsrc, int srcs_on_device,
                void *stream);
+
+/* ---- device-resident sample buffers ---------------------------------------- */
+/* The reference keeps samples in arrays of Float32Array channels over
+ * SharedArrayBuffers that every worker sees (src/buffer-service.js:8-27,
+ * src/mix-worker-thread.js:14-16).  A wp_buf is that array in HBM: nch channels of
+ * `frames` floats, zero-filled on creation like a fresh typed array, shared
+ * between the threads of the process by id, reference-counted.  Channel c starts
+ * at wp_buf_channel(b, c); the "_dev" entry points above take such pointers, so
+ * a bar can go render -> reverb -> mix without leaving the device. */
+wp_buf *wp_buf_create(int nch, int64_t frames);
+/* Process-wide id (> 0) another thread can open; 0 for NULL. */
+uint64_t wp_buf_id(const wp_buf *b);
+/* One more reference to a live buffer, or NULL if the id names none. */
+wp_buf *wp_buf_open(uint64_t id);
+/* Drop one reference; the memory is recycled when the last one goes. */
+void wp_buf_release(wp_buf *b);
+/* which: 0 channels, 1 frames, 2 floats between channels, 3 device, 4 bytes. */
+int64_t wp_buf_info(const wp_buf *b, int which);
+float *wp_buf_channel(const wp_buf *b, int ch);
+/* channel.set(hostArray, dst_off): the worker's copy-back (src/mix-worker-thread.js:23-24)
+ * as an upload.  A span past the end is WP_ERR_RANGE, as TypedArray.set throws. */
+int wp_buf_write(wp_buf *b, int ch, int64_t dst_off, const float *src_host, int64_t n);
+/* Download n frames of one channel. */
+int wp_buf_read(const wp_buf *b, int ch, int64_t src_off, float *dst_host, int64_t n);
+/* dst.set(src) between device channels (src/render.js:45 buffer[1].set(buffer[0]);
+ * overlapping ranges copy as if through a temporary). */
+int wp_buf_copy(wp_buf *dst, int dch, int64_t dst_off, const wp_buf *src, int sch, int64_t src_off, int64_t n,
+                void *stream);
+/* channel.fill(value, off, off+n) (src/context.js:140-143 zero()). */
+int wp_buf_fill(wp_buf *b, int ch, int64_t off, int64_t n, float value, void *stream);
 
 /* ---- integer helpers ------------------------------------------------------ */
 /* lib/ring-buffer.js:10-22,33-50: element a proxy access at `key` touches. */

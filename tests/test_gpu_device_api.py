@@ -48,6 +48,16 @@ def test_node_addon_in_worker_threads():
     assert "ok workers 2" in out.stdout, out.stdout
 
 
+def test_node_device_buffers_match_host_path():
+    """DeviceBuffer in place of Float32Array[] (c.buffer, mixBuffers targets/sources, go input):
+    buffer semantics, go, every mixBuffers source form, mono/stereo block reverb with resume from a
+    cloned cached tail, and worker-thread rendered stems -- bit-identical to the host-array path."""
+    out = subprocess.run([_node(), "--no-warnings", os.path.join(ROOT, "tests", "node", "test_device.mjs")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.strip().startswith("ok device "), out.stdout
+
+
 def test_synth_noise_device_matches_oracle(torch, oracle):
     from dsp_amd import device
     for n, seed, start in [(1000, 7, 0), (4097, 1001, 96000), (12345, 2 ** 31 + 5, 2 ** 31 - 100)]:
@@ -117,6 +127,82 @@ def test_reverb_blocks_device_resident(torch, oracle):
                 assert float(np.abs(got.astype(np.float64) - want[ch]).max()) <= TOL, (b, ch)
     finally:
         capi.lib().wp_reverb_destroy(rv)
+
+
+def test_device_buffers_c_abi_reverb_to_mix_chain(torch, oracle):
+    """wp_buf + wp_reverb_block_to + wp_mix_dev: a stereo bar goes upload -> block reverb (result in
+    a fresh wp_buf per block, carried tail read from the previous one) -> mixed into a device bus,
+    compared with the oracle's impulse_reverb_stereo + mix_buffers.  Also ids, reference counts,
+    fill/copy/read/write and their error codes."""
+    from dsp_amd import capi
+    lib = capi.lib()
+    L, M, offset, blocks = 5000, 3100, 11, 3
+    f32p = C.POINTER(C.c_float)
+    irs = [oracle.synth_ir(M, 80), oracle.synth_ir(M, 81)]
+    irp = (f32p * 2)(*[a.ctypes.data_as(f32p) for a in irs])
+    ir = capi.check_handle(lib.wp_ir_create(irp, 2, M, L), "wp_ir_create")
+    rv = capi.check_handle(lib.wp_reverb_create(ir, 2, (C.c_int32 * 2)(0, 1), offset), "wp_reverb_create")
+
+    def write(buf, ch, arr, off=0):
+        return lib.wp_buf_write(buf, ch, off, arr.ctypes.data_as(f32p), arr.size)
+
+    def read(buf, ch, n, off=0):
+        out = np.empty(n, np.float32)
+        capi.check(lib.wp_buf_read(buf, ch, off, out.ctypes.data_as(f32p), n), "wp_buf_read")
+        return out
+
+    bus = capi.check_handle(lib.wp_buf_create(2, L), "wp_buf_create")
+    bid = lib.wp_buf_id(bus)
+    assert bid > 0 and lib.wp_buf_info(bus, 0) == 2 and lib.wp_buf_info(bus, 1) == L and lib.wp_buf_info(bus, 2) % 64 == 0
+    assert not read(bus, 1, L).any()                                  # fresh buffers are zero
+    again = capi.check_handle(lib.wp_buf_open(bid), "wp_buf_open")
+    assert again == bus and lib.wp_buf_open(bid + 12345) is None
+    lib.wp_buf_release(again)
+    assert write(bus, 0, np.ones(8, np.float32), L - 7) == -2         # RangeError like TypedArray.set
+    assert lib.wp_buf_fill(bus, 2, 0, 1, C.c_float(0), None) == -1    # no such channel
+    capi.check(lib.wp_buf_fill(bus, 0, 10, 5, C.c_float(0.25), None), "wp_buf_fill")
+    capi.check(lib.wp_buf_copy(bus, 1, 100, bus, 0, 8, 10, None), "wp_buf_copy")
+    assert read(bus, 1, 10, 100).tolist() == [0, 0] + [0.25] * 5 + [0, 0, 0]
+    capi.check(lib.wp_buf_fill(bus, 0, 0, L, C.c_float(0), None), "zero")
+    capi.check(lib.wp_buf_fill(bus, 1, 0, L, C.c_float(0), None), "zero")
+
+    store, want_bus = {}, [np.zeros(L, np.float32), np.zeros(L, np.float32)]
+    fn = oracle.impulse_reverb_stereo(oracle.StubContext([np.zeros(L, np.float32)] * 2, 0, {"u": irs}, store), "u", offset=offset)
+    inb = capi.check_handle(lib.wp_buf_create(2, L), "wp_buf_create")
+    keep = []
+    try:
+        for b in range(blocks):
+            xs = [oracle.synth_noise(L, 90, b * L), oracle.synth_noise(L, 91, b * L)]
+            want = fn(oracle.StubContext(xs, b * L, {"u": irs}, store))
+            oracle.mix_buffers(want_bus, [list(want), 1, 0.5, 0])
+            for ch in range(2):
+                capi.check(write(inb, ch, xs[ch]), "wp_buf_write")
+            curr = capi.check_handle(lib.wp_buf_create(2, L + M), "wp_buf_create")
+            keep.append(curr)                                         # the tail is a view into it
+            v = capi.WpReverbView()
+            capi.check(lib.wp_reverb_block_to(rv, lib.wp_buf_channel(inb, 0), lib.wp_buf_info(inb, 2), L,
+                                              lib.wp_buf_channel(curr, 0), lib.wp_buf_info(curr, 2), C.byref(v), None),
+                       "wp_reverb_block_to")
+            src = capi.WpSrc()
+            src.ch[0] = lib.wp_buf_channel(curr, 0) + 4 * v.ret_off
+            src.ch[1] = lib.wp_buf_channel(curr, 1) + 4 * v.ret_off
+            src.nch, src.rl, src.sl, src.vol, src.o = 2, v.ret_len, v.ret_len, 0.5, 0
+            tgt = (C.c_void_p * 2)(lib.wp_buf_channel(bus, 0), lib.wp_buf_channel(bus, 1))
+            capi.check(lib.wp_mix_dev(tgt, 2, L, C.byref(src), 1, 0, None), "wp_mix_dev")
+            for ch in range(2):
+                got = read(curr, ch, v.ret_len, v.ret_off)
+                assert float(np.abs(got.astype(np.float64) - want[ch]).max()) <= TOL, (b, ch)
+            if len(keep) > 2:
+                lib.wp_buf_release(keep.pop(0))                       # recycled through the pool
+        for ch in range(2):
+            assert float(np.abs(read(bus, ch, L).astype(np.float64) - want_bus[ch]).max()) <= TOL
+        assert lib.wp_reverb_tail_len(rv) == M - offset
+    finally:
+        lib.wp_reverb_destroy(rv)
+        lib.wp_ir_destroy(ir)
+        for b_ in keep + [inb, bus]:
+            lib.wp_buf_release(b_)
+    assert lib.wp_buf_open(bid) is None                               # gone with its last reference
 
 
 def test_mix_dev_many_stems_bit_exact(torch, oracle):
