@@ -12,6 +12,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -205,12 +206,34 @@ static int get_tables(int dev, int B, const c32 **out)
 }
 
 // ---------------------------------------------------------------------------
+// Partition spectra built from host samples are shared between handles: every
+// worker thread that receives the same kernel object (lib/impulse-convolve.js:9-13
+// hands it round through the cache) asks for the same spectra, and the second
+// request finds them already in device memory.  Keyed by shape and two independent
+// 64-bit hashes of the samples; reference-counted; immutable once built.
+struct IrShared {
+    c32 *Hp;
+    int refs;
+};
+struct IrKey {
+    int dev, nch, B;
+    int64_t M, L;
+    uint64_t h1, h2;
+    bool operator<(const IrKey &o) const
+    {
+        return std::tie(dev, nch, B, M, L, h1, h2) < std::tie(o.dev, o.nch, o.B, o.M, o.L, o.h1, o.h2);
+    }
+};
+static std::map<IrKey, IrShared> g_ir_cache;  // guarded by g_mu
+
 struct wp_ir {
     int dev;
     int nch;
     int64_t M, L;
     int B, P, Pp, PG;
     c32 *Hp;           // [nch][Pp][B] per-bin partition spectra
+    bool shared;       // Hp belongs to g_ir_cache[key]
+    IrKey key;
     const c32 *tables;
     int64_t bytes;
     wp_conv *single;   // lazily built 1-job plan for wp_convolve / wp_convolve_dev
@@ -270,7 +293,9 @@ static int choose_PG(int P)
     return 24;  // longer IRs run ceil(P/24) accumulating passes of 24 partitions
 }
 
-static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, int64_t M, int64_t L, hipStream_t s)
+// hashes: nullptr, or the two content hashes of the host samples (enables sharing)
+static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, int64_t M, int64_t L, hipStream_t s,
+                               const uint64_t *hashes = nullptr)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) {
@@ -290,6 +315,7 @@ static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, 
     ir->single_ch = 0;
     ir->stage_in = ir->stage_out = nullptr;
     ir->Hp = nullptr;
+    ir->shared = false;
     c32 *Zir = nullptr;
     auto bail = [&](const char *what, hipError_t e) {
         fail(WP_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
@@ -303,6 +329,18 @@ static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, 
         return nullptr;
     }
     const size_t hbytes = sizeof(c32) * (size_t)nch * ir->Pp * ir->B;
+    ir->bytes = (int64_t)hbytes;
+    if (hashes) {
+        ir->key = IrKey{dev, nch, ir->B, M, L, hashes[0], hashes[1]};
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_ir_cache.find(ir->key);
+        if (it != g_ir_cache.end()) {
+            it->second.refs++;
+            ir->Hp = it->second.Hp;
+            ir->shared = true;
+            return ir;
+        }
+    }
     hipError_t e;
     if ((e = hipMalloc((void **)&ir->Hp, hbytes)) != hipSuccess) return bail("hipMalloc(Hp)", e);
     if ((e = hipMemsetAsync(ir->Hp, 0, hbytes, s)) != hipSuccess) return bail("hipMemsetAsync", e);
@@ -313,8 +351,34 @@ static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, 
         return bail("k_hpack", e);
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail("hipStreamSynchronize", e);
     (void)hipFree(Zir);
-    ir->bytes = (int64_t)hbytes;
+    if (hashes) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto ins = g_ir_cache.emplace(ir->key, IrShared{ir->Hp, 1});
+        if (!ins.second) {  // another thread built the same spectra meanwhile: use theirs
+            (void)hipFree(ir->Hp);
+            ins.first->second.refs++;
+            ir->Hp = ins.first->second.Hp;
+        }
+        ir->shared = true;
+    }
     return ir;
+}
+
+static void hash_samples(const float *const *ir, int nch, int64_t M, uint64_t out[2])
+{
+    uint64_t a = 0xcbf29ce484222325ull, b = 0x9e3779b97f4a7c15ull;
+    for (int c = 0; c < nch; c++) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(ir[c]);
+        for (int64_t i = 0; i < M; i++) {
+            uint32_t v;
+            memcpy(&v, &w[i], sizeof(v));
+            a = (a ^ v) * 0x100000001b3ull;                       // FNV-1a over 32-bit words
+            b = (b + v) * 0xff51afd7ed558ccdull; b ^= b >> 29;    // multiply-xorshift chain
+        }
+        a = (a ^ 0xffu) * 0x100000001b3ull;                       // channel separator
+    }
+    out[0] = a;
+    out[1] = b;
 }
 
 static int check_ir_args(int nch, int64_t M, int64_t L)
@@ -359,7 +423,9 @@ extern "C" wp_ir *wp_ir_create(const float *const *ir, int nch, int64_t M, int64
             return nullptr;
         }
     }
-    wp_ir *r = ir_create_common(d, nch, M, M, L, nullptr);
+    uint64_t hashes[2];
+    hash_samples(ir, nch, M, hashes);
+    wp_ir *r = ir_create_common(d, nch, M, M, L, nullptr, hashes);
     (void)hipFree(d);
     return r;
 }
@@ -370,7 +436,16 @@ extern "C" void wp_ir_destroy(wp_ir *ir)
     if (ir->single) wp_conv_destroy(ir->single);
     if (ir->stage_in) (void)hipFree(ir->stage_in);
     if (ir->stage_out) (void)hipFree(ir->stage_out);
-    if (ir->Hp) (void)hipFree(ir->Hp);
+    if (ir->shared) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_ir_cache.find(ir->key);
+        if (it != g_ir_cache.end() && --it->second.refs == 0) {
+            (void)hipFree(it->second.Hp);
+            g_ir_cache.erase(it);
+        }
+    } else if (ir->Hp) {
+        (void)hipFree(ir->Hp);
+    }
     delete ir;
 }
 
@@ -386,6 +461,12 @@ extern "C" int64_t wp_ir_info(const wp_ir *ir, int which)
     case 5: return ir->L + ir->M;
     case 6: return wp_next_pot((int32_t)(ir->L + ir->M));
     case 7: return ir->bytes;
+    case 8: {
+        if (!ir->shared) return 1;
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_ir_cache.find(ir->key);
+        return it == g_ir_cache.end() ? 1 : it->second.refs;
+    }
     }
     return WP_ERR_INVALID;
 }

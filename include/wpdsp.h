@@ -60,13 +60,16 @@ int32_t wp_fft_length(int64_t L, int64_t M);
  * M samples each (host memory): builds the partition spectra on the device.
  * L is the block length the caller convolves with (c.buffer[0].length in
  * lib/impulse-convolve.js:12, impulse-convolve-stereo.js:14-15); it fixes the
- * result length L+M and the partition size.  NULL on failure. */
+ * result length L+M and the partition size.  NULL on failure.  Handles made from
+ * identical samples and lengths share one copy of the spectra in device memory
+ * (the kernel object travels between worker threads through the cache,
+ * lib/impulse-convolve.js:9-13; each thread still gets a handle of its own). */
 wp_ir *wp_ir_create(const float *const *ir, int nch, int64_t M, int64_t L);
 /* Same with the IR already on the device: channel c starts at ir_dev + c*ch_stride. */
 wp_ir *wp_ir_create_dev(const float *ir_dev, int nch, int64_t ch_stride, int64_t M, int64_t L, void *stream);
 void wp_ir_destroy(wp_ir *ir);
 /* which: 0 M, 1 L, 2 channels, 3 partition size B, 4 partitions P, 5 result length L+M,
- * 6 reference FFT length, 7 device bytes held. */
+ * 6 reference FFT length, 7 device bytes of spectra, 8 handles sharing them. */
 int64_t wp_ir_info(const wp_ir *ir, int which);
 
 /* ---- convolution: lib/convolve.js:564-586 fftConvolution(...) -> go(input) - */

@@ -129,6 +129,41 @@ def test_reverb_blocks_device_resident(torch, oracle):
         capi.lib().wp_reverb_destroy(rv)
 
 
+def test_ir_spectra_are_shared_between_handles(torch, oracle):
+    """Two handles built from the same samples (what two worker threads do with one cached kernel
+    object) hold one copy of the spectra; each stays usable after the other is destroyed, and a
+    different IR of the same shape is not confused with it."""
+    from dsp_amd import capi
+    lib = capi.lib()
+    f32p = C.POINTER(C.c_float)
+    L, M = 3000, 2000
+    irs = [oracle.synth_ir(M, 5), oracle.synth_ir(M, 6)]
+    other = [irs[0].copy(), irs[1].copy()]
+    other[1][M // 2] = np.nextafter(other[1][M // 2], np.float32(1))  # one ulp apart
+
+    def make(chs):
+        return capi.check_handle(lib.wp_ir_create((f32p * 2)(*[a.ctypes.data_as(f32p) for a in chs]), 2, M, L), "wp_ir_create")
+
+    def go(h, ch, x):
+        out = np.empty(L + M, np.float32)
+        capi.check(lib.wp_convolve(h, ch, x.ctypes.data_as(f32p), x.size, out.ctypes.data_as(f32p)), "wp_convolve")
+        return out
+
+    x = oracle.synth_noise(L, 9)
+    a, b, c = make(irs), make(irs), make(other)
+    assert lib.wp_ir_info(a, 8) == 2 and lib.wp_ir_info(b, 8) == 2 and lib.wp_ir_info(c, 8) == 1
+    ya = go(a, 1, x)
+    assert np.array_equal(ya.view(np.uint32), go(b, 1, x).view(np.uint32))
+    assert not np.array_equal(ya.view(np.uint32), go(c, 1, x).view(np.uint32))
+    lib.wp_ir_destroy(a)
+    assert lib.wp_ir_info(b, 8) == 1
+    assert np.array_equal(ya.view(np.uint32), go(b, 1, x).view(np.uint32))
+    want = oracle.fft_convolution(L, oracle.fft_process_kernel(L, irs[1]), M)(x)
+    assert float(np.abs(ya.astype(np.float64) - want).max()) <= TOL
+    lib.wp_ir_destroy(b)
+    lib.wp_ir_destroy(c)
+
+
 def test_device_buffers_c_abi_reverb_to_mix_chain(torch, oracle):
     """wp_buf + wp_reverb_block_to + wp_mix_dev: a stereo bar goes upload -> block reverb (result in
     a fresh wp_buf per block, carried tail read from the previous one) -> mixed into a device bus,
