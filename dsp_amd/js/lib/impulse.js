@@ -77,7 +77,7 @@ async function reverb (c, params, nch) {
       prev[1] = view(curr[1], r.prevOff, r.prevLen)
     }
     c.set(prevKey(c.n), prev, 5000)
-    if (isDeviceChannel(curr[0])) keepAlive(Array.from(curr), 5000)
+    if (isDeviceChannel(curr[0])) keepAlive(state, Array.from(curr), 5000)
     const out = Array.from(curr, a => view(a, r.retOff, r.retLen))
     return nch === 1 ? out[0] : out
   }

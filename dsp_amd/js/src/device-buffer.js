@@ -126,13 +126,19 @@ export class DeviceBuffer extends Array {
 
 // Hold a reference to the memory behind `channels` for `ttl` milliseconds: a value
 // handed to a cache that stores clones (c.set(id, value, ttl), src/global-service.js:15-19)
-// must stay openable for as long as the cache may return it.  Expired entries are
-// dropped on the next call; no timer keeps the event loop alive.
+// must stay openable for as long as the cache may return it.  `owner` groups the
+// entries of one producer, of which only the newest `depth` are held (a block loop
+// running faster than real time must not pin one buffer per block for the whole ttl).
+// Expired entries are dropped on the next call; no timer keeps the event loop alive.
 const kept = []
-export const keepAlive = (channels, ttl) => {
+export const keepAlive = (owner, channels, ttl, depth = 2) => {
   const now = Date.now()
-  for (let i = kept.length - 1; i >= 0; i--) if (kept[i].until < now) kept.splice(i, 1)
-  kept.push({ until: now + ttl, handles: channels.map(c => c.h) })
+  let mine = 0
+  for (let i = kept.length - 1; i >= 0; i--) {
+    const k = kept[i]
+    if (k.until < now || (k.owner === owner && ++mine >= depth)) kept.splice(i, 1)
+  }
+  kept.push({ owner, until: now + ttl, handles: channels.map(c => c.h) })
 }
 
 export const isDeviceBuffer = b => Array.isArray(b) && b.length > 0 && isDeviceChannel(b[0])

@@ -370,7 +370,26 @@ static napi_value js_mix_sl(napi_env env, napi_callback_info info)
 // ---- device-resident buffers ----------------------------------------------------
 // A device channel is described from JavaScript as { h: <buffer handle>, ch, off, length }
 // (dsp_amd/js/src/device-buffer.js); it resolves to a device pointer and a frame count.
-static void buf_finalize(napi_env, void *p, void *) { wp_buf_release((wp_buf *)p); }
+// V8 is told how much device memory hangs off each handle, so a loop that drops a
+// buffer per block triggers garbage collection before HBM fills up.
+static void buf_finalize(napi_env env, void *p, void *)
+{
+    int64_t adjusted = 0;
+    napi_adjust_external_memory(env, -wp_buf_info((wp_buf *)p, 4), &adjusted);
+    wp_buf_release((wp_buf *)p);
+}
+
+static napi_value wrap_buf(napi_env env, wp_buf *b)
+{
+    napi_value obj = wrap_ptr(env, b, buf_finalize);
+    if (!obj) {
+        wp_buf_release(b);
+        return NULL;
+    }
+    int64_t adjusted = 0;
+    napi_adjust_external_memory(env, wp_buf_info(b, 4), &adjusted);
+    return obj;
+}
 
 struct DevChan {
     wp_buf *buf;
@@ -419,7 +438,7 @@ static napi_value js_buf_create(napi_env env, napi_callback_info info)
     if (!get_i64(env, argv[0], &nch) || !get_i64(env, argv[1], &frames)) return throw_wp(env, WP_ERR_INVALID);
     wp_buf *b = wp_buf_create((int)nch, frames);
     if (!b) return throw_wp(env, WP_ERR_HIP);
-    return wrap_ptr(env, b, buf_finalize);
+    return wrap_buf(env, b);
 }
 
 // bufOpen(id) -> handle (another reference to a buffer created by any thread)
@@ -430,7 +449,7 @@ static napi_value js_buf_open(napi_env env, napi_callback_info info)
     if (!get_i64(env, argv[0], &id) || id <= 0) return throw_wp(env, WP_ERR_INVALID);
     wp_buf *b = wp_buf_open((uint64_t)id);
     if (!b) return throw_wp(env, WP_ERR_HIP);
-    return wrap_ptr(env, b, buf_finalize);
+    return wrap_buf(env, b);
 }
 
 // bufInfo(handle, which) ; which == -1: the process-wide id
