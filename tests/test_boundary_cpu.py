@@ -110,3 +110,17 @@ def test_node_addon_and_shims_load():
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.startswith("ok load")
+
+
+def test_node_sample_file_ingestion():
+    """RIFF/WAVE reader that stands in for the browser's decodeAudioData in front of c.sample(url)
+    (src/sample-service.js:12-37): PCM 8/16/24/32, float 32/64, extensible header, odd chunks,
+    per-path cache.  Scaling follows the Web Audio rule (divide by 2^(bits-1)); the reference holds
+    no audio fixture, so the expected values are hand-computed: parity unpinned."""
+    node = shutil.which("node")
+    if not node:
+        pytest.skip("node is not available")
+    out = subprocess.run([node, "--no-warnings", os.path.join(ROOT, "tests", "node", "test_sample_file.mjs")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("ok sample-file")
