@@ -95,6 +95,32 @@ def test_batched_convolver_vs_oracle(torch, oracle, L, M, njobs):
     assert float(np.abs(out[0, :L + M].cpu().numpy().astype(np.float64) - want).max()) <= TOL
 
 
+def test_per_track_impulse_responses(torch, oracle):
+    """Every job with an impulse response of its own (one IR handle with as many channels as
+    jobs): results per job against the oracle, and the one-pass reverb+mix against the oracle's
+    mix of those results."""
+    from dsp_amd import device
+    L, M, tracks = 9000, 5200, 5
+    njobs = 2 * tracks
+    irs = np.stack([oracle.synth_ir(M, 300 + j) for j in range(njobs)])
+    ir = device.DeviceIR(torch.from_numpy(irs).cuda(), L)
+    conv = device.BatchedConvolver(ir, list(range(njobs)))
+    x = np.stack([oracle.synth_noise(L, 400 + j) for j in range(njobs)])
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty((njobs, L + M), dtype=torch.float32, device="cuda")
+    bus = torch.zeros((2, L), dtype=torch.float32, device="cuda")
+    vol = [0.5 / (s + 1) for s in range(tracks)]
+    conv.run_and_mix(xd, out, [bus[0], bus[1]], vol)
+    got = out.cpu().numpy()
+    want = [oracle.fft_convolution(L, oracle.fft_process_kernel(L, irs[j]), M)(x[j]) for j in range(njobs)]
+    for j in range(njobs):
+        assert float(np.abs(got[j].astype(np.float64) - want[j]).max()) <= TOL, j
+    want_bus = [np.zeros(L, np.float32), np.zeros(L, np.float32)]
+    oracle.mix_buffers(want_bus, *[[[want[2 * s], want[2 * s + 1]], 1, vol[s], 0] for s in range(tracks)])
+    for ch in range(2):
+        assert float(np.abs(bus[ch].cpu().numpy().astype(np.float64) - want_bus[ch]).max()) <= TOL
+
+
 def test_reverb_blocks_device_resident(torch, oracle):
     """wp_reverb_block_dev over several blocks == the oracle's impulse_reverb_stereo."""
     from dsp_amd import capi, device

@@ -94,12 +94,13 @@ def c4(S=4096):
             "frac_of_8TBs": alg / t / 8e12, "stem_Msamples_per_s": S * 2 * F / t / 1e6, "bytes": alg}
 
 
-def c5(tracks=256):
+def c5(tracks=256, per_track_ir=False):
     F, M = 2880000, 192000
-    irs = np.stack([dev.synth_ir(M, 500000), dev.synth_ir(M, 500001)])
-    ir = dev.DeviceIR(torch.from_numpy(irs).cuda(), F)
     njobs = 2 * tracks
-    conv = dev.BatchedConvolver(ir, [j % 2 for j in range(njobs)])
+    nir = njobs if per_track_ir else 2  # an impulse response per channel-job, or one shared stereo IR
+    irs = np.stack([dev.synth_ir(M, 500000 + c) for c in range(nir)])
+    ir = dev.DeviceIR(torch.from_numpy(irs).cuda(), F)
+    conv = dev.BatchedConvolver(ir, [j % nir for j in range(njobs)])
     x = torch.empty((njobs, F), dtype=torch.float32, device="cuda")
     for j in range(njobs):
         dev.synth_noise(x[j], 1000 + j)
@@ -112,7 +113,9 @@ def c5(tracks=256):
         conv.run_mix(x, [bus[0], bus[1]], vol)
     t = timed(step, 3, 1)
     f, m, i = conv.profile_read()
-    return {"config": "c5 per-GPU share: %d stereo tracks x 60 s x 4 s IR (P=%d)" % (tracks, ir.info(4)), "ms_per_step": t * 1e3,
+    return {"config": "c5 per-GPU share: %d stereo tracks x 60 s x 4 s IR (P=%d), %s" % (
+                tracks, ir.info(4), "%d per-track IRs (%.0f MB of spectra)" % (nir, ir.info(7) / 1e6) if per_track_ir else "shared stereo IR"),
+            "ms_per_step": t * 1e3,
             "Msamples_per_s": njobs * (F + M) / t / 1e6, "kernel_ms": {"fwd": f, "mac(2 groups)": m, "inv_mix": i}}
 
 
@@ -120,5 +123,5 @@ if __name__ == "__main__":
     torch.cuda.set_device(0)
     which = sys.argv[1:] or ["c2", "c4", "c5"]
     for w in which:
-        print(json.dumps({"c2": c2, "c4": c4, "c5": c5}[w]()), flush=True)
+        print(json.dumps({"c2": c2, "c4": c4, "c5": c5, "c5ir": lambda: c5(per_track_ir=True)}[w]()), flush=True)
         torch.cuda.empty_cache()
