@@ -226,7 +226,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC bytes per launch from the committed rocprofv3 passes
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                tj = json.load(open(tpath))
+                # counters are per launch of ONE workload: quote them only for that workload
+                same = tj.get("workload") == {"tracks_per_gpu": tracks, "frames": F, "ir_len": M, "path": a.path}
+                traffic = tj.get(dom) if same else None
             except Exception:
                 traffic = None
         res = {

@@ -57,5 +57,7 @@ for k in acc:
             continue  # the one-off IR-partition launch, not the bench kernel
         traffic[base] = int(2 * f * 1024 + w * 1024)
 print("# traffic bytes per launch (2*FETCH_SIZE + WRITE_SIZE):", traffic)
+# the profiled command is the default bench workload (tools/profile_gpu.sh)
+traffic["workload"] = {"tracks_per_gpu": 256, "frames": 2880000, "ir_len": 96000, "path": "onepass"}
 with open(os.path.join(root, "traffic.json"), "w") as fh:
     json.dump(traffic, fh)
