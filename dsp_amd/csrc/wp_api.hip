@@ -882,6 +882,18 @@ extern "C" int wp_mix_dev(float *const *tgt_dev, int tch, int64_t tl, const wp_s
     if (!tgt_dev || tl < 0 || nsrc < 0 || (nsrc > 0 && !srcs)) return fail(WP_ERR_INVALID, "wp_mix_dev: bad argument");
     if (tch < 1 || !tgt_dev[0] || (tch >= 2 && !tgt_dev[1])) return fail(WP_ERR_INVALID, "wp_mix_dev: null target channel");
     if (nsrc == 0 || tl == 0) return WP_OK;
+    if (!srcs_on_device) {
+        // the kernel updates the target in place while other lanes read the sources: a source
+        // that overlaps the target (a feedback mix in the reference) would race
+        for (int64_t i = 0; i < nsrc; i++) {
+            const wp_src &S = srcs[i];
+            if (S.nch != 1 && S.nch != 2) continue;
+            for (int c = 0; c < S.nch; c++)
+                for (int t = 0; t < tch && t < 2; t++)
+                    if (S.ch[c] && S.ch[c] < tgt_dev[t] + tl && tgt_dev[t] < S.ch[c] + S.rl)
+                        return fail(WP_ERR_UNSUPPORTED, "wp_mix_dev: source %lld overlaps the target in device memory; not implemented", (long long)i);
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));

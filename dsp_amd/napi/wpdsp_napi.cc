@@ -323,6 +323,13 @@ static napi_value js_mix(napi_env env, napi_callback_info info)
         NAPI_CALL(env, napi_get_named_property(env, s, "rl", &v));
         if (!get_i64(env, v, &t)) return throw_wp(env, WP_ERR_INVALID);
         d.rl = t;
+        // rl frames are read from every channel: a shorter second channel (NaN past its end in
+        // the reference) is refused rather than read out of bounds
+        for (size_t c = 0; c < ch.size() && c < 2; c++)
+            if (t < 0 || (int64_t)ch[c].length < t) {
+                napi_throw_type_error(env, NULL, "mix: source channels must all hold source[0].length frames");
+                return NULL;
+            }
         NAPI_CALL(env, napi_get_named_property(env, s, "sl", &v));
         if (!get_i64(env, v, &t)) return throw_wp(env, WP_ERR_INVALID);
         d.sl = t;
@@ -350,7 +357,13 @@ static napi_value js_mix(napi_env env, napi_callback_info info)
         }
     }
     std::vector<float *> tp(tgt.size());
-    for (size_t c = 0; c < tgt.size(); c++) tp[c] = tgt[c].data;
+    for (size_t c = 0; c < tgt.size(); c++) {
+        if (tgt[c].length < tgt[0].length) {
+            napi_throw_type_error(env, NULL, "mix: target channels must all hold target[0].length frames");
+            return NULL;
+        }
+        tp[c] = tgt[c].data;
+    }
     const int rc = wp_mix(tp.data(), (int)tgt.size(), (int64_t)tgt[0].length, srcs.data(), (int64_t)nsrc);
     if (rc) return throw_wp(env, rc);
     return argv[0];
@@ -650,6 +663,12 @@ static napi_value js_mix_dev(napi_env env, napi_callback_info info)
         d.nch = (int32_t)ch.size();
         for (size_t c = 0; c < ch.size() && c < 2; c++) d.ch[c] = ch[c].ptr;
         d.rl = ch.empty() ? 0 : ch[0].len;
+        for (size_t c = 1; c < ch.size() && c < 2; c++)
+            if (ch[c].len < d.rl) {
+                drop_temps();
+                napi_throw_type_error(env, NULL, "mixDev: source channels must all hold source[0].length frames");
+                return NULL;
+            }
         int64_t t;
         double f;
         if (napi_get_named_property(env, s, "sl", &v) != napi_ok || !get_i64(env, v, &t)) { drop_temps(); return throw_wp(env, WP_ERR_INVALID); }
@@ -685,6 +704,11 @@ static napi_value js_mix_dev(napi_env env, napi_callback_info info)
         }
     }
     float *tp[2] = {tgt[0].ptr, tgt.size() > 1 ? tgt[1].ptr : NULL};
+    if (tgt.size() == 2 && tgt[1].len < tl) {
+        drop_temps();
+        napi_throw_type_error(env, NULL, "mixDev: target channels must all hold target[0].length frames");
+        return NULL;
+    }
     int rc = WP_OK;
     if (tgt.size() <= 2) rc = wp_mix_dev(tp, (int)tgt.size(), tl, srcs.data(), (int64_t)nsrc, 0, NULL);
     drop_temps();  // recycled memory is only reused in stream order, after the mix kernel

@@ -179,7 +179,10 @@ int32_t wp_mix_sl(int64_t rl, double length);
 /* Host buffers: tgt[0..tch) of tl floats are updated in place. */
 int wp_mix(float *const *tgt, int tch, int64_t tl, const wp_src *srcs, int64_t nsrc);
 /* Device buffers: every pointer inside tgt_dev/srcs is a device pointer; the
- * srcs array itself is in host memory unless srcs_on_device != 0. */
+ * srcs array itself is in host memory unless srcs_on_device != 0.  The target is
+ * updated in place, so a source must not overlap it (WP_ERR_UNSUPPORTED when the
+ * srcs array is in host memory and shows an overlap; wp_mix, which stages host
+ * arrays, reads an aliased source as it was before the call). */
 int wp_mix_dev(float *const *tgt_dev, int tch, int64_t tl, const wp_src *srcs, int64_t nsrc, int srcs_on_device,
                void *stream);
 

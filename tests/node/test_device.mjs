@@ -89,6 +89,15 @@ const main = async () => {
     }
   }
 
+  // ---- refused rather than undefined: a source that overlaps the device bus, ragged channels
+  {
+    const bus = DeviceBuffer.alloc(2, 100)
+    try { mixBuffers(bus, bus); fail('aliased device mix accepted') } catch (e) { if (!/overlaps the target/.test(e.message)) throw e; checks++ }
+    const ragged = [DeviceBuffer.alloc(1, 100)[0], DeviceBuffer.alloc(1, 50)[0]]
+    try { mixBuffers(bus, ragged); fail('ragged device source accepted') } catch (e) { if (!(e instanceof TypeError)) throw e; checks++ }
+    try { mixBuffers([new Float32Array(100), new Float32Array(100)], [new Float32Array(100), new Float32Array(50)]); fail('ragged host source accepted') } catch (e) { if (!(e instanceof TypeError)) throw e; checks++ }
+  }
+
   // ---- block reverb with c.buffer on the device
   for (const [make, nch] of [[impulseReverb, 1], [impulseReverbStereo, 2]]) {
     for (const offset of [0, 2, 700, 1202]) {
