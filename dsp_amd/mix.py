@@ -42,11 +42,16 @@ def mix_buffers(target, *sources):
     for t in target:
         if t.dtype != np.float32 or not t.flags["C_CONTIGUOUS"]:
             raise TypeError("target channels must be contiguous float32 arrays")
+        if len(t) < tl:
+            raise TypeError("target channels must all hold len(target[0]) frames")
     keep = []
     srcs = (capi.WpSrc * max(len(sources), 1))()
     for i, source in enumerate(sources):
         buf, rl, sl, vol, vec, o = decode_source(source, tl)
         chans = [np.ascontiguousarray(b, dtype=np.float32) for b in buf]
+        if len(chans) in (1, 2) and any(len(c) < rl for c in chans):
+            # rl frames are read from every channel (NaN past a shorter one in the reference)
+            raise TypeError("source channels must all hold len(source[0]) frames")
         keep.append((chans, vec))
         s = srcs[i]
         s.nch = len(chans)
