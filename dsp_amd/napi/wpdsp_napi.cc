@@ -215,8 +215,20 @@ static napi_value js_reverb_create(napi_env env, napi_callback_info info)
     if (!r) return throw_wp(env, WP_ERR_HIP);
     // the reverb borrows the IR: keep the IR object alive as a property of the handle
     napi_value obj = wrap_ptr(env, r, reverb_finalize);
-    if (obj) napi_set_named_property(env, obj, "ir", argv[0]);
+    if (obj) {
+        napi_set_named_property(env, obj, "ir", argv[0]);
+        napi_set_named_property(env, obj, "jobs", num(env, (double)nch));
+    }
     return obj;
+}
+
+// number of channel-jobs a reverb handle was created with (every per-job array must match it)
+static size_t reverb_jobs(napi_env env, napi_value handle)
+{
+    napi_value v;
+    int64_t n = 0;
+    if (napi_get_named_property(env, handle, "jobs", &v) != napi_ok || !get_i64(env, v, &n)) return 0;
+    return (size_t)n;
 }
 
 static bool collect_channels(napi_env env, napi_value arr, std::vector<F32View> *out)
@@ -239,8 +251,8 @@ static napi_value js_reverb_block(napi_env env, napi_callback_info info)
     wp_reverb *r = unwrap<wp_reverb>(env, argv[0]);
     if (!r) return NULL;
     std::vector<F32View> in;
-    if (!collect_channels(env, argv[1], &in) || in.empty()) {
-        napi_throw_type_error(env, NULL, "reverbBlock(handle, [Float32Array, ...])");
+    if (!collect_channels(env, argv[1], &in) || in.empty() || in.size() != reverb_jobs(env, argv[0])) {
+        napi_throw_type_error(env, NULL, "reverbBlock(handle, [one Float32Array per channel])");
         return NULL;
     }
     napi_value irv;
@@ -282,12 +294,18 @@ static napi_value js_reverb_set_tail(napi_env env, napi_callback_info info)
     wp_reverb *r = unwrap<wp_reverb>(env, argv[0]);
     if (!r) return NULL;
     std::vector<F32View> pv;
-    if (!collect_channels(env, argv[1], &pv) || pv.empty()) {
-        napi_throw_type_error(env, NULL, "reverbSetTail(handle, [Float32Array, ...])");
+    if (!collect_channels(env, argv[1], &pv) || pv.empty() || pv.size() != reverb_jobs(env, argv[0])) {
+        napi_throw_type_error(env, NULL, "reverbSetTail(handle, [one Float32Array per channel])");
         return NULL;
     }
     std::vector<const float *> pp(pv.size());
-    for (size_t c = 0; c < pv.size(); c++) pp[c] = pv[c].data;
+    for (size_t c = 0; c < pv.size(); c++) {
+        if (pv[c].length < pv[0].length) {
+            napi_throw_type_error(env, NULL, "reverbSetTail: tails must have equal length");
+            return NULL;
+        }
+        pp[c] = pv[c].data;
+    }
     const int rc = wp_reverb_set_tail(r, pp.data(), (int64_t)pv[0].length);
     if (rc) return throw_wp(env, rc);
     return NULL;
@@ -589,7 +607,7 @@ static napi_value js_reverb_block_to(napi_env env, napi_callback_info info)
     std::vector<DevChan> in, out;
     int64_t is = 0, os = 0;
     if (!collect_dev_chans(env, argv[1], &in) || !collect_dev_chans(env, argv[2], &out) || in.empty() ||
-        in.size() != out.size() || !job_stride(in, &is) || !job_stride(out, &os)) {
+        in.size() != out.size() || in.size() != reverb_jobs(env, argv[0]) || !job_stride(in, &is) || !job_stride(out, &os)) {
         napi_throw_type_error(env, NULL, "reverbBlockTo(state, [in channels], [out channels]): channels of one buffer, equal lengths");
         return NULL;
     }
@@ -622,7 +640,7 @@ static napi_value js_reverb_set_tail_dev(napi_env env, napi_callback_info info)
     if (!r) return NULL;
     std::vector<DevChan> pv;
     int64_t ps = 0;
-    if (!collect_dev_chans(env, argv[1], &pv) || pv.empty() || !job_stride(pv, &ps)) {
+    if (!collect_dev_chans(env, argv[1], &pv) || pv.empty() || pv.size() != reverb_jobs(env, argv[0]) || !job_stride(pv, &ps)) {
         napi_throw_type_error(env, NULL, "reverbSetTailDev(state, [channels of one buffer])");
         return NULL;
     }
