@@ -246,6 +246,7 @@ struct wp_conv {
     int njobs;
     int T;
     int tchunk;
+    bool gather;        // small batch: gather-form MAC (one workgroup per output block) instead of the streaming one
     int32_t *job_irch;  // device
     c32 *Z, *W;
     int64_t bytes;
@@ -498,6 +499,17 @@ extern "C" wp_conv *wp_conv_create(wp_ir *ir, int njobs, const int32_t *job_ch)
         if (want < 1) want = 1;
         c->tchunk = (int)((c->T + want - 1) / want);
     }
+    {
+        // The streaming MAC needs about a workgroup per CU to hide its per-step latency; below
+        // that, and while the block spectra sit in cache, the gather form finishes sooner.
+        const int64_t stream_wgs = (int64_t)(ir->B / 256) * njobs * ((c->T + c->tchunk - 1) / c->tchunk);
+        const int64_t zbytes = (int64_t)sizeof(c32) * njobs * c->T * ir->B;
+        c->gather = stream_wgs < 256 && zbytes <= ((int64_t)64 << 20) && c->T <= 65535;
+        if (const char *e = getenv("WPDSP_MAC")) {
+            if (!strcmp(e, "stream")) c->gather = false;
+            if (!strcmp(e, "gather") && c->T <= 65535) c->gather = true;
+        }
+    }
     c->job_irch = nullptr;
     c->Z = c->W = nullptr;
     c->prof = c->prof_valid = false;
@@ -540,6 +552,7 @@ extern "C" int64_t wp_conv_info(const wp_conv *c, int which)
     case 2: return c->ir->B;
     case 3: return c->ir->Pp;
     case 4: return c->tchunk;
+    case 5: return c->gather ? 1 : 0;
     }
     return WP_ERR_INVALID;
 }
@@ -588,6 +601,9 @@ static int conv_front(wp_conv *c, const float *in_dev, int64_t in_stride, int64_
     if (c->prof) HIPCHK(hipEventRecord(c->ev[1], s));
     if (Tin == 0)  // no input at all: the result is zeros
         HIPCHK(hipMemsetAsync(c->W, 0, sizeof(c32) * (size_t)c->njobs * T * B, s));
+    else if (c->gather)
+        HIPCHK(launch_mac_gather(c->Z, c->W, ir->Hp, ir->tables + table_wsplit_offset(B), c->job_irch, B, T, Tout, Tin,
+                                 ir->Pp, c->njobs, s));
     else
         HIPCHK(launch_mac(ir->PG, c->Z, c->W, ir->Hp, ir->tables + table_wsplit_offset(B), c->job_irch, B, T, Tout, Tin,
                           ir->Pp, c->njobs, c->tchunk, s));

@@ -421,6 +421,49 @@ __global__ __launch_bounds__(256) void k_mac(const c32 *__restrict__ Z, c32 *__r
 }
 
 // ---------------------------------------------------------------------------
+// The same sum in gather form, for batches too small to fill the chip with the
+// streaming kernel above (a stereo reverb block is 2 jobs = 32 workgroups, each a
+// serial chain of T + PG steps).  One workgroup = 256 bins of ONE output block:
+//   W[t] = unsplit( sum_p split(Z[t-p]) * H[p] ),
+// every partition's loads independent and in flight together.  Z is read Pp times,
+// which is why this form is only chosen while the spectra are cache-resident.
+template <int U>
+__global__ __launch_bounds__(256) void k_mac_gather(const c32 *__restrict__ Z, c32 *__restrict__ W,
+                                                    const c32 *__restrict__ Hc, const c32 *__restrict__ wbin,
+                                                    const int32_t *__restrict__ job_irch, int B, int T, int Tin, int Pp)
+{
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    const int k = lane_bin(slot, B);
+    const int job = blockIdx.y;
+    const int t = blockIdx.z;
+    const c32 w = wbin[k];
+    const c32 *zj = Z + (int64_t)job * T * B + k;
+    const c32 *hp = Hc + (int64_t)job_irch[job] * Pp * B + k;
+    const int tin_last = Tin - 1;
+    c32 acc = {0.f, 0.f};
+    for (int p0 = 0; p0 < Pp; p0 += U) {  // Pp is a multiple of 4; U divides it
+        c32 z[U], h[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int tau = t - (p0 + u);
+            const int tc = tau < 0 ? 0 : (tau > tin_last ? tin_last : tau);
+            z[u] = zj[(int64_t)tc * B];
+            h[u] = hp[(int64_t)(p0 + u) * B];
+            if (tau != tc) z[u] = c32{0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const c32 zp = {__shfl_xor(z[u].x, 32), __shfl_xor(z[u].y, 32)};
+            const c32 x = bin_split(z[u], zp, w);
+            acc.x = fmaf(-x.y, h[u].y, fmaf(x.x, h[u].x, acc.x));
+            acc.y = fmaf(x.y, h[u].x, fmaf(x.x, h[u].y, acc.y));
+        }
+    }
+    const c32 yp = {__shfl_xor(acc.x, 32), __shfl_xor(acc.y, 32)};
+    W[((int64_t)job * T + t) * B + k] = bin_unsplit(acc, yp, w);
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 template <int B>
 static hipError_t set_lds_attr(const void *fn)
@@ -550,6 +593,16 @@ hipError_t launch_mac(int PG, const c32 *Z, c32 *W, const c32 *Hp, const c32 *ws
     case 24: return launch_mac_t<24>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, tchunk, s);
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_mac_gather(const c32 *Z, c32 *W, const c32 *Hp, const c32 *wsplit, const int32_t *job_irch, int B,
+                             int T, int Tout, int Tin, int Pp, int njobs, hipStream_t s)
+{
+    if (Tout <= 0) return hipSuccess;
+    if (Tout > 65535 || njobs > 65535) return hipErrorInvalidValue;
+    const dim3 grid(B / 256, njobs, Tout), block(256);
+    hipLaunchKernelGGL((k_mac_gather<4>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tin, Pp);
+    return hipGetLastError();
 }
 
 }  // namespace wp

@@ -113,7 +113,8 @@ int64_t wp_conv_workspace_bytes(const wp_conv *c);
 int wp_conv_profile(wp_conv *c, int enable);
 int wp_conv_profile_read(wp_conv *c, float *ms3);
 /* Geometry of a plan: which = 0 jobs, 1 output blocks T, 2 partition size B,
- * 3 partitions P (padded), 4 blocks per MAC time chunk. */
+ * 3 partitions P (padded), 4 blocks per MAC time chunk, 5 whether the small-batch
+ * (gather) form of the spectral multiply-accumulate is in use. */
 int64_t wp_conv_info(const wp_conv *c, int which);
 
 /* ---- block reverb: lib/impulse-reverb.js:10-21, impulse-reverb-stereo.js:11-30 */

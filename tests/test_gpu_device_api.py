@@ -68,15 +68,21 @@ def test_synth_noise_device_matches_oracle(torch, oracle):
 
 @pytest.mark.parametrize("L,M,njobs", [(5000, 1200, 6), (20000, 9000, 5), (70000, 30000, 3), (4096, 4096, 4), (100, 50000, 2),
                                         (3000, 110000, 2), (1, 1, 1), (700, 7400, 3), (20000, 210000, 2)])
-def test_batched_convolver_vs_oracle(torch, oracle, L, M, njobs):
+@pytest.mark.parametrize("mac", ["stream", "gather"])
+def test_batched_convolver_vs_oracle(torch, oracle, monkeypatch, L, M, njobs, mac):
     """Ragged sizes (L, M not multiples of the partition), several jobs, IR channel map;
     (3000, 110000) needs 27 partitions = two accumulating MAC passes; (1, 1) is the
-    smallest legal FFT; (20000, 210000) uses the 8192-point plan with two passes; (700, 7400) is the small-partition plan with 8 partitions."""
-    from dsp_amd import device
+    smallest legal FFT; (20000, 210000) uses the 8192-point plan with two passes; (700, 7400) is the small-partition plan with 8 partitions.
+    Each case runs with both forms of the spectral multiply-accumulate (the streaming
+    delay-line kernel and the small-batch gather kernel), which the library otherwise
+    picks by batch size."""
+    from dsp_amd import capi, device
+    monkeypatch.setenv("WPDSP_MAC", mac)
     irs = np.stack([oracle.synth_ir(M, 40), oracle.synth_ir(M, 41)])
     ir = device.DeviceIR(torch.from_numpy(irs).cuda(), L)
     job_ch = [(j * 3) % 2 for j in range(njobs)]
     conv = device.BatchedConvolver(ir, job_ch)
+    assert capi.lib().wp_conv_info(conv.handle, 5) == (1 if mac == "gather" else 0)
     x = np.stack([oracle.synth_noise(L, 50 + j) for j in range(njobs)])
     xd = torch.from_numpy(x).cuda()
     stride = L + M + 5  # odd stride: exercises the unaligned store path
