@@ -423,44 +423,63 @@ __global__ __launch_bounds__(256) void k_mac(const c32 *__restrict__ Z, c32 *__r
 // ---------------------------------------------------------------------------
 // The same sum in gather form, for batches too small to fill the chip with the
 // streaming kernel above (a stereo reverb block is 2 jobs = 32 workgroups, each a
-// serial chain of T + PG steps).  One workgroup = 256 bins of ONE output block:
-//   W[t] = unsplit( sum_p split(Z[t-p]) * H[p] ),
-// every partition's loads independent and in flight together.  Z is read Pp times,
-// which is why this form is only chosen while the spectra are cache-resident.
-template <int U>
+// serial chain of T + PG steps).  One workgroup = 256 bins of TB consecutive
+// output blocks:
+//   W[t] = unsplit( sum_p split(Z[t-p]) * H[p] ),   t = t0 .. t0+TB-1,
+// partitions taken G at a time: the TB+G-1 block spectra and G partition spectra
+// a group needs are independent loads, all in flight together.  Z is re-read
+// about Pp/TB times, which is why this form is only chosen while the spectra are
+// cache-resident.
+template <int TB, int G>
 __global__ __launch_bounds__(256) void k_mac_gather(const c32 *__restrict__ Z, c32 *__restrict__ W,
                                                     const c32 *__restrict__ Hc, const c32 *__restrict__ wbin,
-                                                    const int32_t *__restrict__ job_irch, int B, int T, int Tin, int Pp)
+                                                    const int32_t *__restrict__ job_irch, int B, int T, int Tout, int Tin,
+                                                    int Pp)
 {
+    constexpr int NZ = TB + G - 1;
     const int slot = blockIdx.x * 256 + threadIdx.x;
     const int k = lane_bin(slot, B);
     const int job = blockIdx.y;
-    const int t = blockIdx.z;
+    const int t0 = blockIdx.z * TB;
     const c32 w = wbin[k];
     const c32 *zj = Z + (int64_t)job * T * B + k;
     const c32 *hp = Hc + (int64_t)job_irch[job] * Pp * B + k;
     const int tin_last = Tin - 1;
-    c32 acc = {0.f, 0.f};
-    for (int p0 = 0; p0 < Pp; p0 += U) {  // Pp is a multiple of 4; U divides it
-        c32 z[U], h[U];
+    c32 acc[TB];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int tau = t - (p0 + u);
+    for (int j = 0; j < TB; j++) acc[j] = c32{0.f, 0.f};
+    for (int p0 = 0; p0 < Pp; p0 += G) {  // G divides Pp
+        c32 z[NZ], h[G];
+#pragma unroll
+        for (int e = 0; e < NZ; e++) {  // e = 0 is the newest block this group touches
+            const int tau = t0 + (TB - 1) - p0 - e;
             const int tc = tau < 0 ? 0 : (tau > tin_last ? tin_last : tau);
-            z[u] = zj[(int64_t)tc * B];
-            h[u] = hp[(int64_t)(p0 + u) * B];
-            if (tau != tc) z[u] = c32{0.f, 0.f};
+            z[e] = zj[(int64_t)tc * B];
+            if (tau != tc) z[e] = c32{0.f, 0.f};
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const c32 zp = {__shfl_xor(z[u].x, 32), __shfl_xor(z[u].y, 32)};
-            const c32 x = bin_split(z[u], zp, w);
-            acc.x = fmaf(-x.y, h[u].y, fmaf(x.x, h[u].x, acc.x));
-            acc.y = fmaf(x.y, h[u].x, fmaf(x.x, h[u].y, acc.y));
+        for (int u = 0; u < G; u++) h[u] = hp[(int64_t)(p0 + u) * B];
+#pragma unroll
+        for (int e = 0; e < NZ; e++) {
+            const c32 zp = {__shfl_xor(z[e].x, 32), __shfl_xor(z[e].y, 32)};
+            z[e] = bin_split(z[e], zp, w);
+        }
+#pragma unroll
+        for (int j = 0; j < TB; j++) {
+#pragma unroll
+            for (int u = 0; u < G; u++) {  // block t0+j with partition p0+u reads tau = t0+j-p0-u
+                const c32 x = z[(TB - 1) - j + u];
+                acc[j].x = fmaf(-x.y, h[u].y, fmaf(x.x, h[u].x, acc[j].x));
+                acc[j].y = fmaf(x.y, h[u].x, fmaf(x.x, h[u].y, acc[j].y));
+            }
         }
     }
-    const c32 yp = {__shfl_xor(acc.x, 32), __shfl_xor(acc.y, 32)};
-    W[((int64_t)job * T + t) * B + k] = bin_unsplit(acc, yp, w);
+#pragma unroll
+    for (int j = 0; j < TB; j++) {
+        const c32 yp = {__shfl_xor(acc[j].x, 32), __shfl_xor(acc[j].y, 32)};
+        const c32 o = bin_unsplit(acc[j], yp, w);
+        if (t0 + j < Tout) W[((int64_t)job * T + t0 + j) * B + k] = o;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -595,14 +614,32 @@ hipError_t launch_mac(int PG, const c32 *Z, c32 *W, const c32 *Hp, const c32 *ws
     return hipErrorInvalidValue;
 }
 
+template <int TB>
+static hipError_t launch_mac_gather_t(const c32 *Z, c32 *W, const c32 *Hp, const c32 *wsplit, const int32_t *job_irch,
+                                      int B, int T, int Tout, int Tin, int Pp, int njobs, hipStream_t s)
+{
+    const dim3 grid(B / 256, njobs, (Tout + TB - 1) / TB), block(256);
+    if (Pp % 24 == 0)
+        hipLaunchKernelGGL((k_mac_gather<TB, 24>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp);
+    else if (Pp % 12 == 0)
+        hipLaunchKernelGGL((k_mac_gather<TB, 12>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp);
+    else if (Pp % 8 == 0)
+        hipLaunchKernelGGL((k_mac_gather<TB, 8>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp);
+    else
+        hipLaunchKernelGGL((k_mac_gather<TB, 4>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp);
+    return hipGetLastError();
+}
+
 hipError_t launch_mac_gather(const c32 *Z, c32 *W, const c32 *Hp, const c32 *wsplit, const int32_t *job_irch, int B,
                              int T, int Tout, int Tin, int Pp, int njobs, hipStream_t s)
 {
     if (Tout <= 0) return hipSuccess;
-    if (Tout > 65535 || njobs > 65535) return hipErrorInvalidValue;
-    const dim3 grid(B / 256, njobs, Tout), block(256);
-    hipLaunchKernelGGL((k_mac_gather<4>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tin, Pp);
-    return hipGetLastError();
+    if (Tout > 65535 || njobs > 65535 || Pp % 4) return hipErrorInvalidValue;
+    // more output blocks per workgroup share more loads; keep at least a workgroup per CU
+    const int64_t wgs1 = (int64_t)(B / 256) * njobs * Tout;
+    if (wgs1 >= 4 * 256) return launch_mac_gather_t<4>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, s);
+    if (wgs1 >= 2 * 256) return launch_mac_gather_t<2>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, s);
+    return launch_mac_gather_t<1>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, s);
 }
 
 }  // namespace wp
