@@ -265,7 +265,7 @@ def main():
         }
         if fused_extra is not None:
             res["fused_path"] = fused_extra
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.cpu_tracks > 0:
             res["cpu_baseline"] = cpu_baseline(F, M, a.cpu_tracks)
         print(json.dumps(res), flush=True)
     if world > 1:
