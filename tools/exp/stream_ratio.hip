@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void k(const f2 *__restrict__ A, f2 *__restric
     for (int i = 0; i < 8 * R; i++) s += v[i];
 #pragma unroll
     for (int i = 0; i < 8 * Wn; i++) __builtin_nontemporal_store(s + v[i % (8 * R)], b + threadIdx.x + 256 * i);
+    if (Wn == 0 && s.x == 12345.678f) b[threadIdx.x] = s;  // read-only stream: keep the loads alive
 }
 
 template <int R, int Wn>
