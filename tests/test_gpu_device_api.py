@@ -296,6 +296,34 @@ def test_mix_dev_many_stems_bit_exact(torch, oracle):
             assert_bits_equal(got[ch], want[ch].view(np.uint32), "%s ch%d" % (variant, ch))
 
 
+@pytest.mark.parametrize("tch", [2, 1])
+def test_mix_dev_long_target_bit_exact(torch, oracle, tch):
+    """Targets of 2 Mi frames and more take the 4-rows-per-workgroup tiles: whole tiles plus a
+    ragged tail, stereo and mono sources, odd source count, an unaligned source view, constant
+    gains -- bit-exact against the oracle."""
+    from dsp_amd import device
+    F = 512 * 4096 + 4096 + 1234
+    rl = F + 7
+    stems = [oracle.synth_noise(rl, 7000 + i) for i in range(9)]
+    sd = [torch.from_numpy(a).cuda() for a in stems]
+    desc = [{"ch": [sd[0][:F], sd[1][:F]], "vol": 1.0 / 3},
+            {"ch": [sd[2][:F]], "vol": 0.7},
+            {"ch": [sd[3][3:3 + F], sd[4][3:3 + F]], "vol": 1.0},           # 12 bytes off a 16-byte boundary
+            {"ch": [sd[5], sd[6]], "sl": rl, "o": 5, "vol": -1.25},          # contiguous run starting at frame 5
+            {"ch": [sd[7][:F], sd[8][:F]], "vol": 0.5}]
+    srcs = [([stems[0][:F], stems[1][:F]], 1, 1.0 / 3, 0), ([stems[2][:F]], 1, 0.7, 0),
+            [stems[3][3:3 + F], stems[4][3:3 + F]], ([stems[5], stems[6]], 1, -1.25, 5),
+            ([stems[7][:F], stems[8][:F]], 1, 0.5, 0)]
+    init = [oracle.synth_noise(F, 7100 + c) for c in range(tch)]
+    bus = torch.from_numpy(np.stack(init)).cuda()
+    device.DeviceMix(desc).run([bus[c] for c in range(tch)])
+    want = [a.copy() for a in init]
+    oracle.mix_buffers(want, *srcs)
+    got = bus.cpu().numpy()
+    for ch in range(tch):
+        assert_bits_equal(got[ch], want[ch].view(np.uint32), "long target ch%d" % ch)
+
+
 def test_mix_full_size_properties(torch):
     """At the master-reduce size (60 s at 48 kHz, 64 stems here to bound memory):
     mixing k copies of one coarse-grained stem with vol=1/k (k a power of two)
