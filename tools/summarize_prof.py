@@ -26,6 +26,22 @@ for f in sorted(glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv")
             print("%-42s calls %6s  avg %10.1f us  total %10.1f us  %5s%%" % (
                 short(row["Name"]), row["Calls"], float(row["AverageNs"]) / 1e3, float(row["TotalDurationNs"]) / 1e3, row["Percentage"]))
 
+# The stats average above includes the warm-up launch(es), which run cold (first touch of the
+# workspace).  bench.py times only the steps after warm-up, so the figure to compare with its
+# HIP-event timing is the average over the timed launches: every launch after the first WARM.
+WARM = int(os.environ.get("PROF_WARMUP", "2"))
+print("# kernel-trace, per launch (us) and average after the %d warm-up launch(es)" % WARM)
+for f in sorted(glob.glob(os.path.join(root, "stats", "**", "*kernel_trace.csv"), recursive=True)):
+    per = defaultdict(list)
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            per[short(row["Kernel_Name"])].append((int(row["Start_Timestamp"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
+    for k, v in per.items():
+        if not any(t in k for t in ("k_fft_fwd<", "k_fft_inv", "k_mac", "k_mix<")) or len(v) <= WARM:
+            continue
+        d = [x[1] for x in sorted(v)]
+        print("%-42s %s  -> steady avg %10.1f us" % (k, " ".join("%.0f" % x for x in d), sum(d[WARM:]) / len(d[WARM:])))
+
 print("# PMC (per launch averages)")
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for f in sorted(glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
