@@ -254,6 +254,7 @@ struct wp_conv {
     bool prof_valid;
     hipEvent_t ev[4];
     double *vol_dev;    // per-source gains of the fused reverb+mix call
+    std::vector<double> vol_host;  // what vol_dev holds (an unchanged gain table is not uploaded again)
 };
 
 struct wp_reverb {
@@ -644,7 +645,13 @@ static int conv_mix_common(wp_conv *c, const float *in_dev, int64_t in_stride, i
     if (tl == 0 && !out_dev) return WP_OK;
     const int nsrc = c->njobs / 2;
     if (!c->vol_dev) HIPCHK(hipMalloc((void **)&c->vol_dev, sizeof(double) * nsrc));
-    HIPCHK(hipMemcpyAsync(c->vol_dev, vol, sizeof(double) * nsrc, hipMemcpyHostToDevice, s));
+    // a copy from pageable memory makes the host wait for the stream; repeated calls with the
+    // same gains (one per bar) skip it and queue back to back
+    if (c->vol_host.size() != (size_t)nsrc || memcmp(c->vol_host.data(), vol, sizeof(double) * nsrc) != 0) {
+        c->vol_host.clear();  // stays empty if the copy fails
+        HIPCHK(hipMemcpyAsync(c->vol_dev, vol, sizeof(double) * nsrc, hipMemcpyHostToDevice, s));
+        c->vol_host.assign(vol, vol + nsrc);
+    }
     // with per-job results every output block is needed; otherwise only those that reach the bus
     const int Tout = out_dev ? c->T : (int)((tl + ir->B - 1) / ir->B);
     if (int rc = conv_front(c, in_dev, in_stride, in_len, Tout, s)) return rc;

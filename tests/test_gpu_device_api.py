@@ -379,6 +379,14 @@ def test_fused_reverb_mix_is_bit_identical_to_unfused(torch, L, M, tracks, tl):
     assert torch.equal(bus_a.view(torch.int32), bus_c.view(torch.int32))
     assert torch.equal(out[:, :L + M].view(torch.int32), out_c[:, :L + M].view(torch.int32))
     assert (out_c[:, L + M:] == 3.0).all()
+    # the plan remembers the gain table it uploaded last: different gains on the same plan take effect
+    vol2 = [-0.25 * (1 + t) for t in range(tracks)]
+    bus_d = torch.zeros((2, tl), dtype=torch.float32, device="cuda")
+    bus_e = torch.zeros((2, tl), dtype=torch.float32, device="cuda")
+    device.DeviceMix([{"ch": [out[2 * t], out[2 * t + 1]], "rl": L + M, "sl": L + M, "vol": vol2[t]} for t in range(tracks)]).run([bus_d[0], bus_d[1]])
+    conv.run_mix(x, [bus_e[0], bus_e[1]], vol2)
+    torch.cuda.synchronize()
+    assert torch.equal(bus_d.view(torch.int32), bus_e.view(torch.int32))
 
 
 def test_reverb_tail_roundtrip_and_error_paths(torch, oracle):
