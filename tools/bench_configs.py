@@ -8,6 +8,9 @@ c2  stereo impulse-reverb-stereo, 4 bars of 96 000 frames @ 48 kHz, 2 s stereo I
     (device-resident wp_reverb_block_dev, and through the host-pointer API)
 c4  mix-buffers master reduce: S stereo stems x 60 s @ 48 kHz into one stereo bus (pure HBM-bound)
 c5  per-GPU share of the 2048-track render: 256 stereo tracks x 60 s x 4 s IR (P = 47 partitions)
+c5ir  the same with an impulse response per channel-job
+pcie  the bench workload with the hand-over included: inputs start in pinned host memory, every
+      go() result and the bus end in pinned host memory (never the headline figure)
 """
 import ctypes as C
 import json
@@ -119,9 +122,42 @@ def c5(tracks=256, per_track_ir=False):
             "Msamples_per_s": njobs * (F + M) / t / 1e6, "kernel_ms": {"fwd": f, "mac(2 groups)": m, "inv_mix": i}}
 
 
+def pcie(tracks=256):
+    F, M = 2880000, 96000
+    njobs = 2 * tracks
+    irs = np.stack([dev.synth_ir(M, 500000), dev.synth_ir(M, 500001)])
+    ir = dev.DeviceIR(torch.from_numpy(irs).cuda(), F)
+    conv = dev.BatchedConvolver(ir, [j % 2 for j in range(njobs)])
+    x = torch.empty((njobs, F), dtype=torch.float32, device="cuda")
+    for j in range(njobs):
+        dev.synth_noise(x[j], 1000 + j)
+    xh = torch.empty((njobs, F), dtype=torch.float32).pin_memory()
+    xh.copy_(x)
+    out = torch.empty((njobs, F + M), dtype=torch.float32, device="cuda")
+    outh = torch.empty((njobs, F + M), dtype=torch.float32).pin_memory()
+    bus = torch.zeros((2, F), dtype=torch.float32, device="cuda")
+    bush = torch.empty((2, F), dtype=torch.float32).pin_memory()
+    vol = [1.0 / 256] * tracks
+
+    def step():
+        x.copy_(xh, non_blocking=True)
+        bus.zero_()
+        conv.run_and_mix(x, out, [bus[0], bus[1]], vol)
+        outh.copy_(out, non_blocking=True)
+        bush.copy_(bus, non_blocking=True)
+    t = timed(step, 3, 1)
+
+    def up():
+        x.copy_(xh, non_blocking=True)
+    tu = timed(up, 3, 1)
+    return {"config": "bench workload with PCIe hand-over (pinned host memory, copies and compute serialised on one stream)",
+            "ms_per_step": t * 1e3, "Msamples_per_s": njobs * (F + M) / t / 1e6,
+            "h2d_GBs": x.numel() * 4 / tu / 1e9, "bytes_up": x.numel() * 4, "bytes_down": (out.numel() + bus.numel()) * 4}
+
+
 if __name__ == "__main__":
     torch.cuda.set_device(0)
     which = sys.argv[1:] or ["c2", "c4", "c5"]
     for w in which:
-        print(json.dumps({"c2": c2, "c4": c4, "c5": c5, "c5ir": lambda: c5(per_track_ir=True)}[w]()), flush=True)
+        print(json.dumps({"c2": c2, "c4": c4, "c5": c5, "c5ir": lambda: c5(per_track_ir=True), "pcie": pcie}[w]()), flush=True)
         torch.cuda.empty_cache()
