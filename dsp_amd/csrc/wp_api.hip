@@ -194,7 +194,7 @@ static int get_tables(int dev, int B, const c32 **out)
         for (int b = 0; b < B / 256; b++)
             h[512 + b] = {(float)cos(2 * pi * b * 256.0 / B), (float)-sin(2 * pi * b * 256.0 / B)};
         const int ho = table_thalf_offset(B), wo = table_wsplit_offset(B);
-        for (int j = 0; j < 512; j++) h[ho + j] = {(float)cos(pi * j / B), (float)-sin(pi * j / B)};
+        for (int j = 0; j < 1024; j++) h[ho + j] = {(float)cos(pi * j / B), (float)-sin(pi * j / B)};
         for (int q = 0; q < B; q++) h[wo + q] = {(float)cos(pi * (q + 0.5) / B), (float)-sin(pi * (q + 0.5) / B)};
         DevTables t;
         HIPCHK(hipMalloc((void **)&t.d, sizeof(c32) * n));

@@ -45,21 +45,22 @@ __device__ __forceinline__ TwTables<B> load_tables(const c32 *__restrict__ g, c3
     return tw;
 }
 
-// stages 1 and 2 of a three-stage plan, LDS in / LDS exchange between them;
-// on return v holds the inputs of stage 2 already twiddled and transformed.
+// All stages but the last store: stage 0 computes from registers, every later stage
+// exchanges through LDS; on return v holds the LAST stage's inputs already twiddled and
+// transformed (the caller stores them with stage_store<B, LAST, ...>).
 template <int B, bool INV>
 __device__ __forceinline__ void middle_stages(int tid, c32 *v, c32 *lds, const TwTables<B> &tw)
 {
+    constexpr int LAST = FftPlan<B>::NSTAGE - 1;
     stage_compute<B, 0, INV>(tid, v, tw);
-    stage_store<B, 0, INV>(tid, v, [&](int i, c32 val, int, int) { lds[lds_pad(i)] = val; });
-    __syncthreads();
-    stage_load<B, 1>(tid, v, [&](int i) { return lds[lds_pad(i)]; });
-    __syncthreads();
-    stage_compute<B, 1, INV>(tid, v, tw);
-    stage_store<B, 1, INV>(tid, v, [&](int i, c32 val, int, int) { lds[lds_pad(i)] = val; });
-    __syncthreads();
-    stage_load<B, 2>(tid, v, [&](int i) { return lds[lds_pad(i)]; });
-    stage_compute<B, 2, INV>(tid, v, tw);
+    static_for<1, LAST + 1>([&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        stage_store<B, S - 1, INV>(tid, v, [&](int i, c32 val, int, int) { lds[lds_pad(i)] = val; });
+        __syncthreads();
+        stage_load<B, S>(tid, v, [&](int i) { return lds[lds_pad(i)]; });
+        if constexpr (S < LAST) __syncthreads();  // the next store reuses the buffer
+        stage_compute<B, S, INV>(tid, v, tw);
+    });
 }
 
 // ---------------------------------------------------------------------------
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_fwd(const float *__r
     pre_twist<B>(tid, v, tables + table_thalf_offset(B));
     middle_stages<B, false>(tid, v, lds, tw);
     c32 *z = Z + ((int64_t)job * T + t) * B;
-    stage_store<B, 2, false>(tid, v, [&](int i, c32 val, int, int) { st_nt(z + i, val); });
+    stage_store<B, FftPlan<B>::NSTAGE - 1, false>(tid, v, [&](int i, c32 val, int, int) { st_nt(z + i, val); });
 }
 
 // ---------------------------------------------------------------------------
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv(const c32 *__res
     stage_load<B, 0>(tid, v, [&](int n) { return ld_nt(w + n); });
     middle_stages<B, true>(tid, v, lds, tw);
 
-    constexpr int R = FftPlan<B>::radix(2);
+    constexpr int LAST = FftPlan<B>::NSTAGE - 1, R = FftPlan<B>::radix(LAST);
     float *y = out + (int64_t)job * out_stride;
     const float *pv = prev ? prev + (int64_t)job * prev_stride : nullptr;
     const int64_t o0 = (int64_t)t * B;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv(const c32 *__res
                       (!pv || prev_len <= o0 || (o0 + B <= prev_len && (reinterpret_cast<uintptr_t>(pv + o0) & 7) == 0));
     const bool addp = pv && o0 + B <= prev_len;
     const c32 *thalf = tables + table_thalf_offset(B);
-    stage_store<B, 2, true>(tid, v, [&](int i, c32 val, auto tt, auto) {
+    stage_store<B, LAST, true>(tid, v, [&](int i, c32 val, auto tt, auto) {
         if constexpr (int(tt) >= R / 2) {  // only the second half of the block is output
             val = post_twist<B, int(tt)>(val, thalf[i & (B / R - 1)]);
             const int64_t o = o0 + 2 * (int64_t)(i - B / 2);
@@ -182,7 +183,8 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv_mix(const c32 *_
     extern __shared__ __align__(16) unsigned char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
     c32 *tws = lds + lds_points<B>();
-    constexpr int PT = FftPlan<B>::PT, R = FftPlan<B>::radix(2), NT = B / PT, NS = B / R;
+    constexpr int LAST = FftPlan<B>::NSTAGE - 1;
+    constexpr int PT = FftPlan<B>::PT, R = FftPlan<B>::radix(LAST), NT = B / PT, NS = B / R;
     constexpr int NO = PT / 2;  // complex outputs per thread that belong to the block's second half
     const int tid = threadIdx.x;
     const int t = blockIdx.x;
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv_mix(const c32 *_
         middle_stages<B, true>(tid, v, lds, tw);
         float *y = WRITE ? out + (int64_t)(2 * src + ch) * out_stride : nullptr;
         const bool fullw = WRITE && (o0 + B <= out_len) && ((reinterpret_cast<uintptr_t>(y + o0) & 7) == 0);
-        stage_store<B, 2, true>(tid, v, [&](int i, c32 val, auto tt, auto u) {
+        stage_store<B, LAST, true>(tid, v, [&](int i, c32 val, auto tt, auto u) {
             if constexpr (int(tt) >= R / 2) {
                 val = post_twist<B, int(tt)>(val, thalf[i & (NS - 1)]);
                 if constexpr (WRITE) {
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv_mix(const c32 *_
     };
 
     // two register sets: the next source's spectrum is in flight while this one is transformed
-    // (with 32 points per thread a second set would spill, so that plan loads in place)
+    // (capping the 512-thread plan at 128 VGPRs for a second workgroup per CU measured 2x slower)
     if constexpr (PT <= 16) {
         c32 v[PT], vn[PT];
         fetch(0, vn);

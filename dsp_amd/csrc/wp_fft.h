@@ -152,10 +152,13 @@ struct FftPlan<4096> {
     static constexpr int PT = 16, NSTAGE = 3;
     static constexpr int radix(int) { return 16; }
 };
+// 8192 points: 512 threads x 16 points and four stages (16*8*8*8).  The three-stage
+// alternative (256 threads x 32 points, last radix 32) needs 136-256 VGPRs per thread and
+// leaves one or two workgroups per CU.
 template <>
 struct FftPlan<8192> {
-    static constexpr int PT = 32, NSTAGE = 3;
-    static constexpr int radix(int s) { return s == 2 ? 32 : 16; }
+    static constexpr int PT = 16, NSTAGE = 4;
+    static constexpr int radix(int s) { return s == 0 ? 16 : 8; }
 };
 template <int B>
 constexpr int plan_ns(int s)  // product of the radices before stage s
@@ -184,7 +187,7 @@ struct TwTables {
     const c32 *thi;
 };
 template <int B>
-constexpr int tw_table_points() { return 256 + 256 + B / 256; }  // + thalf[256] + wbin[B] follow in the device block
+constexpr int tw_table_points() { return 256 + 256 + B / 256; }  // thalf[1024] and wbin[B] follow in the device block
 
 template <int B, int NT_TW /* Ns*R of the stage */, bool INV>
 WP_HD c32 stage_twiddle(const TwTables<B> &tw, int m /* t*k < NT_TW */)

@@ -17,10 +17,11 @@ constexpr size_t fft_lds_bytes()
 
 // device table block for one partition size B:
 //   [0,256) t256 | [256,512) tlo | [512, 512+B/256) thi
-//   | thalf[512] = exp(-i*pi*j/B) | wbin[B] = exp(-i*pi*(k+1/2)/B)
+//   | thalf[1024] = exp(-i*pi*j/B) | wbin[B] = exp(-i*pi*(k+1/2)/B)
+// (thalf is indexed by j < max(B/PT, B/last radix): at most 1024 for the plans in wp_fft.h)
 __host__ __device__ inline int table_thalf_offset(int B) { return 512 + B / 256; }
-__host__ __device__ inline int table_wsplit_offset(int B) { return 512 + B / 256 + 512; }
-inline int table_total_points(int B) { return 512 + B / 256 + 512 + B; }
+__host__ __device__ inline int table_wsplit_offset(int B) { return 512 + B / 256 + 1024; }
+inline int table_total_points(int B) { return 512 + B / 256 + 1024 + B; }
 
 hipError_t launch_fft_fwd(int B, bool irmode, const float *in, int64_t in_stride, int64_t in_len, c32 *Z, int T,
                           int nblocks, int njobs, const c32 *tables, hipStream_t s);

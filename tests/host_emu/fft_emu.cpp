@@ -57,10 +57,12 @@ double test_fft()
         a[lds_pad(i)] = {(float)x[i].real(), (float)x[i].imag()};
         x[i] = cd(a[lds_pad(i)].x, a[lds_pad(i)].y);
     }
-    static_assert(FftPlan<B>::NSTAGE == 3, "emu drives three stages");
-    run_stage<B, 0, INV>(regs, a, b, T.tw);
-    run_stage<B, 1, INV>(regs, b, a, T.tw);
-    run_stage<B, 2, INV>(regs, a, b, T.tw);
+    // every stage of the plan, ping-ponging between the two buffers; the result ends in b
+    static_for<0, FftPlan<B>::NSTAGE>([&](auto sc) {
+        run_stage<B, decltype(sc)::value, INV>(regs, a, b, T.tw);
+        a.swap(b);
+    });
+    a.swap(b);
     // reference: O(B^2) double DFT on a subset of bins (all bins for small B)
     double maxerr = 0, maxmag = 0;
     const int stepk = B > 2048 ? 7 : 1;
@@ -85,8 +87,8 @@ double test_odft()
 {
     Tables<B> T;
     constexpr int PT = FftPlan<B>::PT, NT = B / PT;
-    std::vector<c32> thalf(512), wbin(B);
-    for (int j = 0; j < 512; j++) thalf[j] = {(float)cos(M_PI * j / B), (float)-sin(M_PI * j / B)};
+    std::vector<c32> thalf(1024), wbin(B);
+    for (int j = 0; j < 1024; j++) thalf[j] = {(float)cos(M_PI * j / B), (float)-sin(M_PI * j / B)};
     for (int k = 0; k < B; k++) wbin[k] = {(float)cos(M_PI * (k + 0.5) / B), (float)-sin(M_PI * (k + 0.5) / B)};
     std::vector<double> r(2 * B);
     srand(11 * B);
@@ -100,8 +102,11 @@ double test_odft()
         stage_compute<B, 0, false>(tid, v, T.tw);
         stage_store<B, 0, false>(tid, v, [&](int i, c32 val, int, int) { a[lds_pad(i)] = val; });
     }
-    run_stage<B, 1, false>(regs, a, b, T.tw);
-    run_stage<B, 2, false>(regs, b, a, T.tw);
+    constexpr int LAST = FftPlan<B>::NSTAGE - 1;
+    static_for<1, LAST + 1>([&](auto sc) {  // result of each stage lands in b, then becomes the next input a
+        run_stage<B, decltype(sc)::value, false>(regs, a, b, T.tw);
+        a.swap(b);
+    });
     std::vector<c32> R2(B);
     for (int k = 0; k < B; k++) R2[k] = bin_split(a[lds_pad(k)], a[lds_pad(B - 1 - k)], wbin[k]);
     double maxerr = 0;
@@ -113,14 +118,16 @@ double test_odft()
     }
     // inverse: Y = R2 -> Z' -> stages -> post-twist
     for (int k = 0; k < B; k++) b[lds_pad(k)] = bin_unsplit(R2[k], R2[B - 1 - k], wbin[k]);
-    run_stage<B, 0, true>(regs, b, a, T.tw);
-    run_stage<B, 1, true>(regs, a, b, T.tw);
-    constexpr int R = FftPlan<B>::radix(2);
+    static_for<0, LAST>([&](auto sc) {
+        run_stage<B, decltype(sc)::value, true>(regs, b, a, T.tw);
+        a.swap(b);
+    });
+    constexpr int R = FftPlan<B>::radix(LAST);
     std::vector<c32> out(B);
-    for (int tid = 0; tid < NT; tid++) stage_load<B, 2>(tid, &regs[tid * PT], [&](int i) { return b[lds_pad(i)]; });
+    for (int tid = 0; tid < NT; tid++) stage_load<B, LAST>(tid, &regs[tid * PT], [&](int i) { return b[lds_pad(i)]; });
     for (int tid = 0; tid < NT; tid++) {
-        stage_compute<B, 2, true>(tid, &regs[tid * PT], T.tw);
-        stage_store<B, 2, true>(tid, &regs[tid * PT], [&](int i, c32 val, auto tt, auto) {
+        stage_compute<B, LAST, true>(tid, &regs[tid * PT], T.tw);
+        stage_store<B, LAST, true>(tid, &regs[tid * PT], [&](int i, c32 val, auto tt, auto) {
             out[i] = post_twist<B, int(tt)>(val, thalf[i & (B / R - 1)]);
         });
     }
