@@ -870,13 +870,16 @@ extern "C" int wp_reverb_get_tail(wp_reverb *r, float *const *prev_out)
 // different stream first waits for the previous call's stream, because its kernels may
 // still be reading the area.
 struct Scratch {
-    void *p = nullptr;
+    void *p = nullptr;     // device: wp_src copy + mix_desc array
+    void *hpin = nullptr;  // pinned host mirror of the wp_src part (a copy from pinned memory does not stall the host)
     size_t cap = 0;
     hipStream_t last = nullptr;
     bool used = false;
+    hipEvent_t ev = nullptr;  // recorded after the last upload from hpin
+    bool ev_pending = false;
 };
 
-static int mix_scratch(int dev, size_t bytes, hipStream_t s, void **out)
+static int mix_scratch(int dev, size_t bytes, hipStream_t s, Scratch **out)
 {
     static thread_local std::map<int, Scratch> scratch;  // released with the process
     Scratch &sc = scratch[dev];
@@ -885,16 +888,20 @@ static int mix_scratch(int dev, size_t bytes, hipStream_t s, void **out)
         if (sc.p) {
             HIPCHK(hipStreamSynchronize(s));
             HIPCHK(hipFree(sc.p));
-            sc.p = nullptr;
+            HIPCHK(hipHostFree(sc.hpin));
+            sc.p = sc.hpin = nullptr;
             sc.cap = 0;
+            sc.ev_pending = false;
         }
         size_t cap = bytes < (1 << 20) ? (1 << 20) : bytes;
         HIPCHK(hipMalloc(&sc.p, cap));
+        HIPCHK(hipHostMalloc(&sc.hpin, cap, hipHostMallocDefault));
+        if (!sc.ev) HIPCHK(hipEventCreateWithFlags(&sc.ev, hipEventDisableTiming));
         sc.cap = cap;
     }
     sc.last = s;
     sc.used = true;
-    *out = sc.p;
+    *out = &sc;
     return WP_OK;
 }
 
@@ -922,11 +929,17 @@ extern "C" int wp_mix_dev(float *const *tgt_dev, int tch, int64_t tl, const wp_s
     HIPCHK(hipGetDevice(&dev));
     const size_t src_bytes = (sizeof(wp_src) * (size_t)nsrc + 255) & ~(size_t)255;
     const size_t bytes = src_bytes + mix_scratch_bytes(nsrc);
-    void *scr = nullptr;
-    if (int rc = mix_scratch(dev, bytes, s, &scr)) return rc;
+    Scratch *sc = nullptr;
+    if (int rc = mix_scratch(dev, bytes, s, &sc)) return rc;
+    void *scr = sc->p;
     const wp_src *sd = srcs;
     if (!srcs_on_device) {
-        HIPCHK(hipMemcpyAsync(scr, srcs, sizeof(wp_src) * (size_t)nsrc, hipMemcpyHostToDevice, s));
+        // through the pinned mirror: the previous upload must have left it before it is rewritten
+        if (sc->ev_pending) HIPCHK(hipEventSynchronize(sc->ev));
+        memcpy(sc->hpin, srcs, sizeof(wp_src) * (size_t)nsrc);
+        HIPCHK(hipMemcpyAsync(scr, sc->hpin, sizeof(wp_src) * (size_t)nsrc, hipMemcpyHostToDevice, s));
+        HIPCHK(hipEventRecord(sc->ev, s));
+        sc->ev_pending = true;
         sd = reinterpret_cast<const wp_src *>(scr);
     }
     HIPCHK(launch_mix(tgt_dev[0], tch >= 2 ? tgt_dev[1] : nullptr, tch, tl, sd, (char *)scr + src_bytes, nsrc, s));
