@@ -238,12 +238,17 @@ struct wp_ir {
     int64_t bytes;
     wp_conv *single;   // lazily built 1-job plan for wp_convolve / wp_convolve_dev
     int single_ch;     // IR channel that plan currently names
+    wp_conv *wrap;     // 1-job plan with a longer result, for inputs that wrap in the reference's FFT
+    float *wrap_lin;   // its linear-convolution result, wrap_len floats
+    int64_t wrap_len;
+    int wrap_ch;
     float *stage_in, *stage_out;
 };
 
 struct wp_conv {
     wp_ir *ir;
     int njobs;
+    int64_t out_len;    // samples per job result: L+M (longer only for the library's own wrap plan)
     int T;
     int tchunk;
     bool gather;        // small batch: gather-form MAC (one workgroup per output block) instead of the streaming one
@@ -315,6 +320,10 @@ static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, 
     ir->Pp = ((ir->P + ir->PG - 1) / ir->PG) * ir->PG;
     ir->single = nullptr;
     ir->single_ch = 0;
+    ir->wrap = nullptr;
+    ir->wrap_lin = nullptr;
+    ir->wrap_len = 0;
+    ir->wrap_ch = 0;
     ir->stage_in = ir->stage_out = nullptr;
     ir->Hp = nullptr;
     ir->shared = false;
@@ -436,6 +445,8 @@ extern "C" void wp_ir_destroy(wp_ir *ir)
 {
     if (!ir) return;
     if (ir->single) wp_conv_destroy(ir->single);
+    if (ir->wrap) wp_conv_destroy(ir->wrap);
+    if (ir->wrap_lin) (void)hipFree(ir->wrap_lin);
     if (ir->stage_in) (void)hipFree(ir->stage_in);
     if (ir->stage_out) (void)hipFree(ir->stage_out);
     if (ir->shared) {
@@ -474,7 +485,14 @@ extern "C" int64_t wp_ir_info(const wp_ir *ir, int which)
 }
 
 // ---------------------------------------------------------------------------
+static wp_conv *conv_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t out_len);
+
 extern "C" wp_conv *wp_conv_create(wp_ir *ir, int njobs, const int32_t *job_ch)
+{
+    return conv_create(ir, njobs, job_ch, ir ? ir->L + ir->M : 0);
+}
+
+static wp_conv *conv_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t out_len)
 {
     if (need_device()) return nullptr;
     if (!ir || njobs < 1 || njobs > 65535 || !job_ch) {
@@ -489,7 +507,8 @@ extern "C" wp_conv *wp_conv_create(wp_ir *ir, int njobs, const int32_t *job_ch)
     wp_conv *c = new wp_conv();
     c->ir = ir;
     c->njobs = njobs;
-    c->T = (int)((ir->L + ir->M + ir->B - 1) / ir->B);
+    c->out_len = out_len;
+    c->T = (int)((out_len + ir->B - 1) / ir->B);
     // time chunks: enough threads to fill the chip when there are few jobs
     {
         const int64_t per_job = ir->B;
@@ -579,13 +598,20 @@ extern "C" int wp_conv_profile_read(wp_conv *c, float *ms3)
     return WP_OK;
 }
 
-static int check_in_len(const wp_ir *ir, int64_t in_len)
+// true when the reference's N-point circular convolution of this input differs from the
+// linear one inside the first L+M samples it returns (lib/convolve.js:571-582)
+static bool input_wraps(const wp_ir *ir, int64_t in_len)
+{
+    return in_len > ir->L && in_len + ir->M - 1 > wp_next_pot((int32_t)(ir->L + ir->M));
+}
+
+static int check_in_len(const wp_ir *ir, int64_t in_len, bool wrap_ok = false)
 {
     const int64_t N = wp_next_pot((int32_t)(ir->L + ir->M));
     if (in_len < 0) return fail(WP_ERR_INVALID, "negative input length");
     if (in_len > N) return fail(WP_ERR_RANGE, "offset is out of bounds: input of %lld samples exceeds the FFT length %lld", (long long)in_len, (long long)N);
-    if (in_len > ir->L && in_len + ir->M - 1 > N)
-        return fail(WP_ERR_UNSUPPORTED, "input of %lld samples wraps circularly in the reference's %lld-point FFT; not implemented", (long long)in_len, (long long)N);
+    if (!wrap_ok && input_wraps(ir, in_len))
+        return fail(WP_ERR_UNSUPPORTED, "input of %lld samples wraps circularly in the reference's %lld-point FFT; only wp_convolve and wp_convolve_dev implement that", (long long)in_len, (long long)N);
     return WP_OK;
 }
 
@@ -619,11 +645,11 @@ extern "C" int wp_conv_run_dev(wp_conv *c, const float *in_dev, int64_t in_strid
     if (int rc = need_device()) return rc;
     if (!c || !out_dev || (!in_dev && in_len > 0)) return fail(WP_ERR_INVALID, "wp_conv_run_dev: null argument");
     const wp_ir *ir = c->ir;
-    if (int rc = check_in_len(ir, in_len)) return rc;
+    if (int rc = check_in_len(ir, in_len, c->out_len != ir->L + ir->M)) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (int rc = conv_front(c, in_dev, in_stride, in_len, c->T, s)) return rc;
-    if (prev_dev && prev_len > ir->L + ir->M) prev_len = ir->L + ir->M;
-    HIPCHK(launch_fft_inv(ir->B, c->W, c->T, c->njobs, out_dev, out_stride, ir->L + ir->M,
+    if (prev_dev && prev_len > c->out_len) prev_len = c->out_len;
+    HIPCHK(launch_fft_inv(ir->B, c->W, c->T, c->njobs, out_dev, out_stride, c->out_len,
                           prev_len > 0 ? prev_dev : nullptr, prev_stride, prev_len, ir->tables, s));
     if (c->prof) {
         HIPCHK(hipEventRecord(c->ev[3], s));
@@ -697,12 +723,43 @@ static int single_plan(wp_ir *ir, int ch)
     return WP_OK;
 }
 
+// An input longer than L whose linear convolution runs past the reference's FFT length N:
+// the reference returns the first L+M samples of the N-point CIRCULAR convolution, i.e.
+// y[i] = lin[i] + lin[i+N].  in_len <= N and M <= N, so the linear result (in_len+M samples)
+// wraps at most once.  Computed with a longer-result plan of the same partition spectra.
+static int convolve_wrapped(wp_ir *ir, int ch, const float *in_dev, int64_t in_len, float *out_dev, hipStream_t s)
+{
+    const int64_t N = wp_next_pot((int32_t)(ir->L + ir->M));
+    const int64_t lin_len = in_len + ir->M;
+    if (!ir->wrap || ir->wrap_len < lin_len) {
+        if (ir->wrap) wp_conv_destroy(ir->wrap);
+        if (ir->wrap_lin) (void)hipFree(ir->wrap_lin);
+        ir->wrap = nullptr;
+        ir->wrap_lin = nullptr;
+        ir->wrap_len = 0;
+        const int64_t cap = N + ir->M;  // the longest linear result any legal input can have
+        ir->wrap = conv_create(ir, 1, &ch, cap);
+        if (!ir->wrap) return WP_ERR_HIP;
+        ir->wrap_ch = ch;
+        HIPCHK(hipMalloc((void **)&ir->wrap_lin, sizeof(float) * (size_t)(cap + 2)));
+        ir->wrap_len = cap;
+    }
+    if (ir->wrap_ch != ch) {
+        HIPCHK(hipMemcpy(ir->wrap->job_irch, &ch, sizeof(int32_t), hipMemcpyHostToDevice));
+        ir->wrap_ch = ch;
+    }
+    if (int rc = wp_conv_run_dev(ir->wrap, in_dev, 0, in_len, ir->wrap_lin, 0, nullptr, 0, 0, s)) return rc;
+    HIPCHK(launch_wrap_add(ir->wrap_lin, lin_len, N, out_dev, ir->L + ir->M, s));
+    return WP_OK;
+}
+
 extern "C" int wp_convolve_dev(wp_ir *ir, int ch, const float *in_dev, int64_t in_len, float *out_dev, void *stream)
 {
     if (int rc = need_device()) return rc;
     if (!ir || !out_dev || (!in_dev && in_len > 0)) return fail(WP_ERR_INVALID, "wp_convolve_dev: null argument");
     if (ch < 0 || ch >= ir->nch) return fail(WP_ERR_INVALID, "wp_convolve_dev: IR channel %d of %d", ch, ir->nch);
-    if (int rc = check_in_len(ir, in_len)) return rc;
+    if (int rc = check_in_len(ir, in_len, true)) return rc;
+    if (input_wraps(ir, in_len)) return convolve_wrapped(ir, ch, in_dev, in_len, out_dev, (hipStream_t)stream);
     if (int rc = single_plan(ir, ch)) return rc;
     return wp_conv_run_dev(ir->single, in_dev, 0, in_len, out_dev, 0, nullptr, 0, 0, stream);
 }
@@ -712,7 +769,7 @@ extern "C" int wp_convolve(wp_ir *ir, int ch, const float *in, int64_t in_len, f
     if (int rc = need_device()) return rc;
     if (!ir || !out || (!in && in_len > 0)) return fail(WP_ERR_INVALID, "wp_convolve: null argument");
     if (ch < 0 || ch >= ir->nch) return fail(WP_ERR_INVALID, "wp_convolve: IR channel %d of %d", ch, ir->nch);
-    if (int rc = check_in_len(ir, in_len)) return rc;
+    if (int rc = check_in_len(ir, in_len, true)) return rc;
     const int64_t N = wp_next_pot((int32_t)(ir->L + ir->M));
     if (!ir->stage_in) {
         HIPCHK(hipMalloc((void **)&ir->stage_in, sizeof(float) * (size_t)(N + 2)));

@@ -28,6 +28,8 @@ hipError_t launch_fft_fwd(int B, bool irmode, const float *in, int64_t in_stride
 hipError_t launch_fft_inv(int B, const c32 *W, int T, int njobs, float *out, int64_t out_stride, int64_t out_len,
                           const float *prev, int64_t prev_stride, int64_t prev_len, const c32 *tables, hipStream_t s);
 hipError_t launch_hpack(const c32 *Zir, c32 *Hc, const c32 *wbin, int B, int P, int Pp, int nch, hipStream_t s);
+// out[i] = lin[i] + lin[i+N] (second term while i+N < lin_len), i < out_len
+hipError_t launch_wrap_add(const float *lin, int64_t lin_len, int64_t N, float *out, int64_t out_len, hipStream_t s);
 hipError_t launch_mac_gather(const c32 *Z, c32 *W, const c32 *Hc, const c32 *wbin, const int32_t *job_irch, int B,
                              int T, int Tout, int Tin, int Pp, int njobs, hipStream_t s);
 hipError_t launch_mac(int PG, const c32 *Z, c32 *W, const c32 *Hc, const c32 *wbin, const int32_t *job_irch,

@@ -356,4 +356,22 @@ hipError_t launch_synth_noise(float *out, int64_t n, uint32_t seed, int64_t star
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// circular wrap of a linear convolution result at the reference's FFT length N
+__global__ void k_wrap_add(const float *__restrict__ lin, int64_t lin_len, int64_t N, float *__restrict__ out, int64_t out_len)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= out_len) return;
+    float v = i < lin_len ? lin[i] : 0.0f;
+    if (i + N < lin_len) v += lin[i + N];
+    out[i] = v;
+}
+
+hipError_t launch_wrap_add(const float *lin, int64_t lin_len, int64_t N, float *out, int64_t out_len, hipStream_t s)
+{
+    if (out_len <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_wrap_add, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, s, lin, lin_len, N, out, out_len);
+    return hipGetLastError();
+}
+
 }  // namespace wp

@@ -74,7 +74,10 @@ int64_t wp_ir_info(const wp_ir *ir, int which);
 
 /* ---- convolution: lib/convolve.js:564-586 fftConvolution(...) -> go(input) - */
 /* One go(input): ch picks the IR channel; in_len <= reference FFT length, else
- * WP_ERR_RANGE; out receives exactly L+M floats. */
+ * WP_ERR_RANGE; out receives exactly L+M floats.  An input longer than L whose
+ * convolution runs past the FFT length comes back wrapped, as the reference's
+ * circular convolution returns it (the batched and block entry points below
+ * answer WP_ERR_UNSUPPORTED for such inputs). */
 int wp_convolve(wp_ir *ir, int ch, const float *in, int64_t in_len, float *out);
 /* The same with input and result in device memory (in_len floats in, L+M out). */
 int wp_convolve_dev(wp_ir *ir, int ch, const float *in_dev, int64_t in_len, float *out_dev, void *stream);

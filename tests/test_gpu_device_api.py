@@ -427,8 +427,17 @@ def test_reverb_tail_roundtrip_and_error_paths(torch, oracle):
     x = oracle.synth_noise(800, 3)
     want = oracle.fft_convolution(600, oracle.fft_process_kernel(600, oracle.synth_ir(200, 7)), 200)(x)
     assert float(np.abs(go(x).astype(np.float64) - want).max()) <= TOL
-    with pytest.raises(NotImplementedError):                          # ... 1000 + 200 - 1 > 1024 wraps: refused, not mis-computed
-        go(oracle.synth_noise(1000, 3))
+    ogo = oracle.fft_convolution(600, oracle.fft_process_kernel(600, oracle.synth_ir(200, 7)), 200)
+    for n in (1000, 826, 1024, 999):                                  # ... n + 200 - 1 > 1024: the head carries the wrapped tail
+        xw = oracle.synth_noise(n, 3)
+        assert float(np.abs(go(xw).astype(np.float64) - ogo(xw)).max()) <= TOL, n
+    assert float(np.abs(go(x).astype(np.float64) - want).max()) <= TOL  # and the ordinary plan still answers afterwards
+    # the batched entry point still refuses such an input instead of mis-computing it
+    plan = capi.check_handle(lib.wp_conv_create(go.ir.handle, 1, (C.c_int32 * 1)(0)), "wp_conv_create")
+    xin = torch.zeros(1000, dtype=torch.float32, device="cuda")
+    yout = torch.zeros(800, dtype=torch.float32, device="cuda")
+    assert lib.wp_conv_run_dev(plan, C.c_void_p(xin.data_ptr()), 0, 1000, C.c_void_p(yout.data_ptr()), 0, None, 0, 0, None) == -6
+    lib.wp_conv_destroy(plan)
     with pytest.raises(IndexError):
         go(oracle.synth_noise(1025, 3))
     bad = (C.c_int32 * 1)(2)
