@@ -504,16 +504,16 @@ template <int B>
 static hipError_t launch_fwd_t(bool irmode, const float *in, int64_t in_stride, int64_t in_len, c32 *Z, int T,
                                int nblocks, int njobs, const c32 *tables, hipStream_t s)
 {
-    if (fft_lds_bytes<B>() > 48 * 1024) {  // opt in to more than the default dynamic LDS
+    if ((fft_lds_bytes<B, false>()) > 48 * 1024) {  // opt in to more than the default dynamic LDS
         hipError_t e = irmode ? set_lds_attr<B>((const void *)k_fft_fwd<B, true>)
                               : set_lds_attr<B>((const void *)k_fft_fwd<B, false>);
         if (e != hipSuccess) return e;
     }
     const dim3 grid(nblocks, njobs), block(B / FftPlan<B>::PT);
     if (irmode)
-        hipLaunchKernelGGL((k_fft_fwd<B, true>), grid, block, fft_lds_bytes<B>(), s, in, in_stride, in_len, Z, T, tables);
+        hipLaunchKernelGGL((k_fft_fwd<B, true>), grid, block, (fft_lds_bytes<B, false>()), s, in, in_stride, in_len, Z, T, tables);
     else
-        hipLaunchKernelGGL((k_fft_fwd<B, false>), grid, block, fft_lds_bytes<B>(), s, in, in_stride, in_len, Z, T, tables);
+        hipLaunchKernelGGL((k_fft_fwd<B, false>), grid, block, (fft_lds_bytes<B, false>()), s, in, in_stride, in_len, Z, T, tables);
     return hipGetLastError();
 }
 
@@ -534,12 +534,12 @@ static hipError_t launch_inv_t(const c32 *W, int T, int njobs, float *out, int64
                                const float *prev, int64_t prev_stride, int64_t prev_len, const c32 *tables,
                                hipStream_t s)
 {
-    if (fft_lds_bytes<B>() > 48 * 1024) {
+    if ((fft_lds_bytes<B, false>()) > 48 * 1024) {
         hipError_t e = set_lds_attr<B>((const void *)k_fft_inv<B>);
         if (e != hipSuccess) return e;
     }
     const dim3 grid(T, njobs), block(B / FftPlan<B>::PT);
-    hipLaunchKernelGGL((k_fft_inv<B>), grid, block, fft_lds_bytes<B>(), s, W, T, out, out_stride, out_len, prev,
+    hipLaunchKernelGGL((k_fft_inv<B>), grid, block, (fft_lds_bytes<B, false>()), s, W, T, out, out_stride, out_len, prev,
                        prev_stride, prev_len, tables);
     return hipGetLastError();
 }

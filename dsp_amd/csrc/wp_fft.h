@@ -168,11 +168,14 @@ constexpr int plan_ns(int s)  // product of the radices before stage s
     return ns;
 }
 
-// LDS layout: one float2 of padding after every 16, so that a thread writing
-// 16 consecutive outputs (first stage) lands each lane on its own bank pair.
-WP_HD int lds_pad(int i) { return i + (i >> 4); }
+// LDS layout: no padding; the low four index bits are XORed with the next four.  With
+// ds_write_b64 banking over 16-lane groups (32 banks) and ds_read_b64 over 32-lane groups
+// (64 banks), every exchange pattern of the plans above -- a thread storing 16 consecutive
+// outputs, stride-NS stores, loads of consecutive j -- is then conflict-free, where one pad
+// element per 16 left the loads two-way conflicted.
+WP_HD int lds_pad(int i) { return i ^ ((i >> 4) & 15); }
 template <int B>
-constexpr int lds_points() { return B + (B >> 4); }
+constexpr int lds_points() { return B; }
 
 // Twiddle tables for one B (all f32 roundings of f64 values, built on the host):
 //   t256[a] = exp(-2*pi*i*a/256)        a < 256   (stages whose Ns*R <= 256)

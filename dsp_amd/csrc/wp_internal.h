@@ -9,10 +9,12 @@
 
 namespace wp {
 
-template <int B>
+// dynamic LDS of an FFT kernel: the exchange buffer, plus the twiddle tables for the
+// kernels that stage them (TABLES)
+template <int B, bool TABLES = true>
 constexpr size_t fft_lds_bytes()
 {
-    return sizeof(c32) * (size_t)(lds_points<B>() + tw_table_points<B>());
+    return sizeof(c32) * (size_t)(lds_points<B>() + (TABLES ? tw_table_points<B>() : 0));
 }
 
 // device table block for one partition size B:
