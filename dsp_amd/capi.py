@@ -83,6 +83,8 @@ PROTOTYPES = {
     "wp_ring_pos": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "wp_ring_advance": (C.c_int64, [C.c_int64, C.c_int64]),
     "wp_beat_rate": (C.c_int64, [C.c_double, C.c_double]),
+    "wp_bpm_from_beat_rate": (C.c_double, [C.c_double, C.c_int64]),
+    "wp_tune": (C.c_int, [C.c_int, C.c_int64]),
     "wp_synth_noise_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint32, C.c_int64, C.c_void_p]),
     "wp_synth_ir": (C.c_int, [f32p, C.c_int64, C.c_uint32]),
 }

@@ -102,17 +102,19 @@ extern "C" int32_t wp_mix_sl(int64_t rl, double length)
 
 extern "C" int64_t wp_ring_pos(int64_t needle, int64_t key, int64_t length)
 {
+    if (length <= 0) return -1;  // the reference's wrap yields NaN (or never ends) on an empty array: no element
     int64_t pos = needle;
     if (key != 0) {
         pos += key;
         if (pos > length - 1) pos = pos % length;
-        else if (pos < 0 && length > 0) pos = ((pos % length) + length) % length;
+        else if (pos < 0) pos = ((pos % length) + length) % length;
     }
     return pos;
 }
 
 extern "C" int64_t wp_ring_advance(int64_t needle, int64_t length)
 {
+    if (length <= 0) return -1;
     needle++;
     if (needle > length - 1) needle = 0;
     return needle;
@@ -120,7 +122,34 @@ extern "C" int64_t wp_ring_advance(int64_t needle, int64_t length)
 
 extern "C" int64_t wp_beat_rate(double sample_rate, double bpm)
 {
-    return (int64_t)floor(sample_rate * (60.0 / bpm) + 0.5);
+    // Math.round(x) = floor(x + 0.5) except that x + 0.5 must not round up across an integer
+    // (x = 0.49999999999999994) and huge x has no fraction to round
+    const double x = sample_rate * (60.0 / bpm);
+    if (!isfinite(x) || fabs(x) >= 9.0e18) return -1;  // Infinity / NaN beat rate (bpm 0): no block length
+    double r = floor(x);
+    if (x - r >= 0.5) r += 1.0;
+    return (int64_t)r;
+}
+
+// Number.prototype.toFixed(6) followed by parseFloat, for |x| < 1e21: the multiple of 1e-6
+// nearest to the exact value of x (ties away from zero, as the specification's "pick the
+// larger n"), then the double nearest to that decimal.
+static double js_to_fixed6(double x)
+{
+    if (!isfinite(x) || fabs(x) >= 9.0e9) return x;  // beyond 2^53 / 1e6 the scaled value has no fraction left to round
+    const double ax = fabs(x);
+    const double p = ax * 1.0e6;
+    const double e = fma(ax, 1.0e6, -p);  // ax * 1e6 == p + e exactly
+    double n = floor(p);
+    const double f = p - n;               // exact
+    if (f > 0.5 || (f == 0.5 && e >= 0.0)) n += 1.0;
+    const double r = n / 1.0e6;           // correctly rounded quotient = nearest double to the decimal string
+    return x < 0 ? -r : r;
+}
+
+extern "C" double wp_bpm_from_beat_rate(double sample_rate, int64_t beat_rate)
+{
+    return js_to_fixed6(60.0 * (sample_rate / (double)beat_rate));
 }
 
 // TypedArray.prototype.subarray(begin, end) index clamping
@@ -252,8 +281,14 @@ struct wp_conv {
     int T;
     int tchunk;
     bool gather;        // small batch: gather-form MAC (one workgroup per output block) instead of the streaming one
-    int32_t *job_irch;  // device
+    int32_t *job_irch;  // device table of each job's IR channel; nullptr for one-job plans, whose
+    int irch_all;       // channel travels as a launch argument (it changes from call to call)
     c32 *Z, *W;
+    // one stream at a time may use a plan (Z and W are shared by its calls): a call on a
+    // different stream than the previous one first waits for that call's last kernel
+    hipStream_t last_stream;
+    bool used;
+    hipEvent_t done;
     int64_t bytes;
     bool prof;
     bool prof_valid;
@@ -276,12 +311,37 @@ struct wp_reverb {
     int64_t stage_in_len;
 };
 
+// process-wide overrides set through wp_tune (0 = the library's own choice)
+static int g_tune_B = 0, g_tune_PG = 0, g_tune_mac = 0;
+static long g_tune_pool_mb = 2048;
+
+extern "C" int wp_tune(int what, int64_t value)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    switch (what) {
+    case WP_TUNE_PARTITION:
+        if (value != 0 && value != 1024 && value != 2048 && value != 4096 && value != 8192) break;
+        g_tune_B = (int)value;
+        return WP_OK;
+    case WP_TUNE_MAC_GROUP:
+        if (value != 0 && value != 4 && value != 8 && value != 12 && value != 16 && value != 24) break;
+        g_tune_PG = (int)value;
+        return WP_OK;
+    case WP_TUNE_MAC_FORM:
+        if (value < 0 || value > 2) break;
+        g_tune_mac = (int)value;
+        return WP_OK;
+    case WP_TUNE_POOL_MB:
+        if (value < 0 || value > (1 << 20)) break;
+        g_tune_pool_mb = (long)value;
+        return WP_OK;
+    }
+    return fail(WP_ERR_INVALID, "wp_tune: knob %d does not take the value %lld", what, (long long)value);
+}
+
 static int choose_B(int64_t L, int64_t M)
 {
-    if (const char *e = getenv("WPDSP_B")) {
-        const int b = atoi(e);
-        if (b == 1024 || b == 2048 || b == 4096 || b == 8192) return b;
-    }
+    if (g_tune_B) return g_tune_B;
     if (L + M <= 8192) return 1024;
     // one MAC pass covers 24 partitions: IRs longer than 24*4096 samples use the larger partition
     return (M > 24 * 4096) ? 8192 : 4096;
@@ -289,10 +349,7 @@ static int choose_B(int64_t L, int64_t M)
 
 static int choose_PG(int P)
 {
-    if (const char *e = getenv("WPDSP_PG")) {
-        const int g = atoi(e);
-        if (g == 4 || g == 8 || g == 12 || g == 16 || g == 24) return g;
-    }
+    if (g_tune_PG) return g_tune_PG;
     if (P <= 4) return 4;
     if (P <= 8) return 8;
     if (P <= 12) return 12;
@@ -492,19 +549,10 @@ extern "C" wp_conv *wp_conv_create(wp_ir *ir, int njobs, const int32_t *job_ch)
     return conv_create(ir, njobs, job_ch, ir ? ir->L + ir->M : 0);
 }
 
-static wp_conv *conv_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t out_len)
+// Geometry of a plan (everything but its device memory): output blocks, MAC time chunks and
+// which form of the spectral multiply-accumulate runs.
+static void plan_geometry(wp_conv *c, wp_ir *ir, int njobs, int64_t out_len)
 {
-    if (need_device()) return nullptr;
-    if (!ir || njobs < 1 || njobs > 65535 || !job_ch) {
-        fail(WP_ERR_INVALID, "wp_conv_create: bad argument (njobs must be 1..65535)");
-        return nullptr;
-    }
-    for (int j = 0; j < njobs; j++)
-        if (job_ch[j] < 0 || job_ch[j] >= ir->nch) {
-            fail(WP_ERR_INVALID, "wp_conv_create: job %d names IR channel %d of %d", j, job_ch[j], ir->nch);
-            return nullptr;
-        }
-    wp_conv *c = new wp_conv();
     c->ir = ir;
     c->njobs = njobs;
     c->out_len = out_len;
@@ -525,27 +573,52 @@ static wp_conv *conv_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t
         const int64_t stream_wgs = (int64_t)(ir->B / 256) * njobs * ((c->T + c->tchunk - 1) / c->tchunk);
         const int64_t zbytes = (int64_t)sizeof(c32) * njobs * c->T * ir->B;
         c->gather = stream_wgs < 256 && zbytes <= ((int64_t)64 << 20) && c->T <= 65535;
-        if (const char *e = getenv("WPDSP_MAC")) {
-            if (!strcmp(e, "stream")) c->gather = false;
-            if (!strcmp(e, "gather") && c->T <= 65535) c->gather = true;
-        }
+        if (g_tune_mac == 1) c->gather = false;
+        if (g_tune_mac == 2 && c->T <= 65535) c->gather = true;
     }
     c->job_irch = nullptr;
+    c->irch_all = 0;
     c->Z = c->W = nullptr;
+    c->bytes = 0;
     c->prof = c->prof_valid = false;
     for (auto &e : c->ev) e = nullptr;
     c->vol_dev = nullptr;
+    c->last_stream = nullptr;
+    c->used = false;
+    c->done = nullptr;
+}
+
+static wp_conv *conv_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t out_len)
+{
+    if (need_device()) return nullptr;
+    if (!ir || njobs < 1 || njobs > 65535 || !job_ch) {
+        fail(WP_ERR_INVALID, "wp_conv_create: bad argument (njobs must be 1..65535)");
+        return nullptr;
+    }
+    for (int j = 0; j < njobs; j++)
+        if (job_ch[j] < 0 || job_ch[j] >= ir->nch) {
+            fail(WP_ERR_INVALID, "wp_conv_create: job %d names IR channel %d of %d", j, job_ch[j], ir->nch);
+            return nullptr;
+        }
+    wp_conv *c = new wp_conv();
+    plan_geometry(c, ir, njobs, out_len);
     const size_t sbytes = sizeof(c32) * (size_t)njobs * c->T * ir->B;
-    hipError_t e = hipMalloc((void **)&c->job_irch, sizeof(int32_t) * njobs);
-    if (e == hipSuccess) e = hipMemcpy(c->job_irch, job_ch, sizeof(int32_t) * njobs, hipMemcpyHostToDevice);
+    hipError_t e = hipSuccess;
+    if (njobs == 1) {
+        c->irch_all = job_ch[0];
+    } else {
+        e = hipMalloc((void **)&c->job_irch, sizeof(int32_t) * njobs);
+        if (e == hipSuccess) e = hipMemcpy(c->job_irch, job_ch, sizeof(int32_t) * njobs, hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&c->Z, sbytes);
     if (e == hipSuccess) e = hipMalloc((void **)&c->W, sbytes);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
     if (e != hipSuccess) {
         fail(WP_ERR_HIP, "wp_conv_create: allocating %zu bytes of spectra failed: %s", 2 * sbytes, hipGetErrorString(e));
         wp_conv_destroy(c);
         return nullptr;
     }
-    c->bytes = (int64_t)(2 * sbytes + sizeof(int32_t) * njobs);
+    c->bytes = (int64_t)(2 * sbytes + (c->job_irch ? sizeof(int32_t) * njobs : 0));
     return c;
 }
 
@@ -556,9 +629,27 @@ extern "C" void wp_conv_destroy(wp_conv *c)
     if (c->Z) (void)hipFree(c->Z);
     if (c->W) (void)hipFree(c->W);
     if (c->vol_dev) (void)hipFree(c->vol_dev);
+    if (c->done) (void)hipEventDestroy(c->done);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     delete c;
+}
+
+// Stream hand-over of a plan: Z, W and the gain table are shared by every call, so a call
+// on another stream than the last one waits (on the device) for that call to finish.
+static int plan_enter(wp_conv *c, hipStream_t s)
+{
+    if (c->done && c->used && c->last_stream != s) HIPCHK(hipStreamWaitEvent(s, c->done, 0));
+    return WP_OK;
+}
+static int plan_leave(wp_conv *c, hipStream_t s)
+{
+    if (c->done) {
+        HIPCHK(hipEventRecord(c->done, s));
+        c->last_stream = s;
+        c->used = true;
+    }
+    return WP_OK;
 }
 
 extern "C" int64_t wp_conv_workspace_bytes(const wp_conv *c) { return c ? c->bytes : WP_ERR_INVALID; }
@@ -629,11 +720,11 @@ static int conv_front(wp_conv *c, const float *in_dev, int64_t in_stride, int64_
     if (Tin == 0)  // no input at all: the result is zeros
         HIPCHK(hipMemsetAsync(c->W, 0, sizeof(c32) * (size_t)c->njobs * T * B, s));
     else if (c->gather)
-        HIPCHK(launch_mac_gather(c->Z, c->W, ir->Hp, ir->tables + table_wsplit_offset(B), c->job_irch, B, T, Tout, Tin,
-                                 ir->Pp, c->njobs, s));
+        HIPCHK(launch_mac_gather(c->Z, c->W, ir->Hp, ir->tables + table_wsplit_offset(B), c->job_irch, c->irch_all, B, T,
+                                 Tout, Tin, ir->Pp, c->njobs, s));
     else
-        HIPCHK(launch_mac(ir->PG, c->Z, c->W, ir->Hp, ir->tables + table_wsplit_offset(B), c->job_irch, B, T, Tout, Tin,
-                          ir->Pp, c->njobs, c->tchunk, s));
+        HIPCHK(launch_mac(ir->PG, c->Z, c->W, ir->Hp, ir->tables + table_wsplit_offset(B), c->job_irch, c->irch_all, B, T,
+                          Tout, Tin, ir->Pp, c->njobs, c->tchunk, s));
     if (c->prof) HIPCHK(hipEventRecord(c->ev[2], s));
     return WP_OK;
 }
@@ -647,6 +738,7 @@ extern "C" int wp_conv_run_dev(wp_conv *c, const float *in_dev, int64_t in_strid
     const wp_ir *ir = c->ir;
     if (int rc = check_in_len(ir, in_len, c->out_len != ir->L + ir->M)) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = plan_enter(c, s)) return rc;
     if (int rc = conv_front(c, in_dev, in_stride, in_len, c->T, s)) return rc;
     if (prev_dev && prev_len > c->out_len) prev_len = c->out_len;
     HIPCHK(launch_fft_inv(ir->B, c->W, c->T, c->njobs, out_dev, out_stride, c->out_len,
@@ -655,7 +747,7 @@ extern "C" int wp_conv_run_dev(wp_conv *c, const float *in_dev, int64_t in_strid
         HIPCHK(hipEventRecord(c->ev[3], s));
         c->prof_valid = true;
     }
-    return WP_OK;
+    return plan_leave(c, s);
 }
 
 static int conv_mix_common(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len, float *out_dev,
@@ -670,6 +762,7 @@ static int conv_mix_common(wp_conv *c, const float *in_dev, int64_t in_stride, i
     if (int rc = check_in_len(ir, in_len)) return rc;
     if (tl == 0 && !out_dev) return WP_OK;
     const int nsrc = c->njobs / 2;
+    if (int rc = plan_enter(c, s)) return rc;
     if (!c->vol_dev) HIPCHK(hipMalloc((void **)&c->vol_dev, sizeof(double) * nsrc));
     // a copy from pageable memory makes the host wait for the stream; repeated calls with the
     // same gains (one per bar) skip it and queue back to back
@@ -687,7 +780,7 @@ static int conv_mix_common(wp_conv *c, const float *in_dev, int64_t in_stride, i
         HIPCHK(hipEventRecord(c->ev[3], s));
         c->prof_valid = true;
     }
-    return WP_OK;
+    return plan_leave(c, s);
 }
 
 extern "C" int wp_conv_mix_run_dev(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len,
@@ -716,10 +809,8 @@ static int single_plan(wp_ir *ir, int ch)
         if (!ir->single) return WP_ERR_HIP;
         ir->single_ch = 0;
     }
-    if (ir->single_ch != ch) {
-        HIPCHK(hipMemcpy(ir->single->job_irch, &ch, sizeof(int32_t), hipMemcpyHostToDevice));
-        ir->single_ch = ch;
-    }
+    ir->single->irch_all = ch;  // a launch argument of the MAC: nothing on the device changes between calls
+    ir->single_ch = ch;
     return WP_OK;
 }
 
@@ -744,10 +835,8 @@ static int convolve_wrapped(wp_ir *ir, int ch, const float *in_dev, int64_t in_l
         HIPCHK(hipMalloc((void **)&ir->wrap_lin, sizeof(float) * (size_t)(cap + 2)));
         ir->wrap_len = cap;
     }
-    if (ir->wrap_ch != ch) {
-        HIPCHK(hipMemcpy(ir->wrap->job_irch, &ch, sizeof(int32_t), hipMemcpyHostToDevice));
-        ir->wrap_ch = ch;
-    }
+    ir->wrap->irch_all = ch;
+    ir->wrap_ch = ch;
     if (int rc = wp_conv_run_dev(ir->wrap, in_dev, 0, in_len, ir->wrap_lin, 0, nullptr, 0, 0, s)) return rc;
     HIPCHK(launch_wrap_add(ir->wrap_lin, lin_len, N, out_dev, ir->L + ir->M, s));
     return WP_OK;
@@ -1110,12 +1199,8 @@ static size_t g_pool_bytes = 0;
 
 static size_t pool_limit()
 {
-    static const size_t lim = [] {
-        const char *e = getenv("WPDSP_POOL_MB");
-        const long mb = e ? atol(e) : 2048;
-        return (size_t)(mb < 0 ? 0 : mb) << 20;
-    }();
-    return lim;
+    std::lock_guard<std::mutex> lk(g_mu);
+    return (size_t)g_tune_pool_mb << 20;
 }
 
 extern "C" wp_buf *wp_buf_create(int nch, int64_t frames)
@@ -1261,14 +1346,34 @@ extern "C" int wp_buf_copy(wp_buf *dst, int dch, int64_t dst_off, const wp_buf *
     const float *s = src->p + (size_t)sch * src->stride + src_off;
     if (d == s) return WP_OK;
     if ((d < s + n) && (s < d + n)) {
-        // TypedArray.set copies as if through a temporary when the ranges overlap
-        float *tmp = nullptr;
-        HIPCHK(hipMalloc((void **)&tmp, sizeof(float) * (size_t)n));
-        hipError_t e = hipMemcpyAsync(tmp, s, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d, tmp, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
-        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-        (void)hipFree(tmp);
-        if (e != hipSuccess) return fail(WP_ERR_HIP, "wp_buf_copy: %s", hipGetErrorString(e));
+        // TypedArray.set copies as if through a temporary when the ranges overlap.  The temporary
+        // is a grow-only area per calling thread and device; a later overlapping copy waits for
+        // the one before it (an event, not a stream synchronisation) before it reuses the area.
+        static thread_local struct Tmp {
+            float *p = nullptr;
+            size_t cap = 0;
+            int dev = -1;
+            hipEvent_t ev = nullptr;
+            bool pending = false;
+        } tmp;
+        const size_t bytes = sizeof(float) * (size_t)n;
+        if (tmp.pending) {
+            HIPCHK(hipEventSynchronize(tmp.ev));
+            tmp.pending = false;
+        }
+        if (tmp.cap < bytes || tmp.dev != dst->dev) {
+            if (tmp.p) (void)hipFree(tmp.p);
+            tmp.p = nullptr;
+            tmp.cap = 0;
+            HIPCHK(hipMalloc((void **)&tmp.p, bytes < (1 << 20) ? (1 << 20) : bytes));
+            tmp.cap = bytes < (1 << 20) ? (1 << 20) : bytes;
+            tmp.dev = dst->dev;
+        }
+        if (!tmp.ev) HIPCHK(hipEventCreateWithFlags(&tmp.ev, hipEventDisableTiming));
+        HIPCHK(hipMemcpyAsync(tmp.p, s, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        HIPCHK(hipMemcpyAsync(d, tmp.p, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        HIPCHK(hipEventRecord(tmp.ev, (hipStream_t)stream));
+        tmp.pending = true;
         return WP_OK;
     }
     HIPCHK(hipMemcpyAsync(d, s, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -330,8 +330,8 @@ __global__ void k_hpack(const c32 *__restrict__ Zir, c32 *__restrict__ Hc, const
 template <int PG, bool ACCUM>
 __global__ __launch_bounds__(256) void k_mac(const c32 *__restrict__ Z, c32 *__restrict__ W,
                                              const c32 *__restrict__ Hc, const c32 *__restrict__ wbin,
-                                             const int32_t *__restrict__ job_irch, int B, int T, int Tout, int Tin,
-                                             int Pp, int p0, int tchunk)
+                                             const int32_t *__restrict__ job_irch, int irch_all, int B, int T,
+                                             int Tout, int Tin, int Pp, int p0, int tchunk)
 {
     constexpr int D = (ACCUM && PG == 24) ? 4 : WP_MAC_DEPTH(PG);  // the accumulating pass carries a second ring: keep it at 3 waves per SIMD
     static_assert(PG % D == 0, "ring");
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void k_mac(const c32 *__restrict__ Z, c32 *__r
     const int ta = blockIdx.z * tchunk;
     const int tb = (ta + tchunk < Tout) ? ta + tchunk : Tout;  // only blocks [0, Tout) are needed
     const c32 w = wbin[k];
-    const int irch = job_irch[job];
+    const int irch = job_irch ? job_irch[job] : irch_all;  // no table: every job uses channel irch_all
 
     c32 h[PG];
     {
@@ -443,8 +443,8 @@ __global__ __launch_bounds__(256) void k_mac(const c32 *__restrict__ Z, c32 *__r
 template <int TB, int G>
 __global__ __launch_bounds__(256) void k_mac_gather(const c32 *__restrict__ Z, c32 *__restrict__ W,
                                                     const c32 *__restrict__ Hc, const c32 *__restrict__ wbin,
-                                                    const int32_t *__restrict__ job_irch, int B, int T, int Tout, int Tin,
-                                                    int Pp)
+                                                    const int32_t *__restrict__ job_irch, int irch_all, int B, int T,
+                                                    int Tout, int Tin, int Pp)
 {
     constexpr int NZ = TB + G - 1;
     const int slot = blockIdx.x * 256 + threadIdx.x;
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void k_mac_gather(const c32 *__restrict__ Z, c
     const int t0 = blockIdx.z * TB;
     const c32 w = wbin[k];
     const c32 *zj = Z + (int64_t)job * T * B + k;
-    const c32 *hp = Hc + (int64_t)job_irch[job] * Pp * B + k;
+    const c32 *hp = Hc + (int64_t)(job_irch ? job_irch[job] : irch_all) * Pp * B + k;
     const int tin_last = Tin - 1;
     c32 acc[TB];
 #pragma unroll
@@ -598,58 +598,58 @@ hipError_t launch_hpack(const c32 *Zir, c32 *Hc, const c32 *wbin, int B, int P, 
 
 template <int PG>
 static hipError_t launch_mac_t(const c32 *Z, c32 *W, const c32 *Hp, const c32 *wsplit, const int32_t *job_irch,
-                               int B, int T, int Tout, int Tin, int Pp, int njobs, int tchunk, hipStream_t s)
+                               int irch_all, int B, int T, int Tout, int Tin, int Pp, int njobs, int tchunk, hipStream_t s)
 {
     const int nchunks = (Tout + tchunk - 1) / tchunk;
     const dim3 grid(B / 256, njobs, nchunks), block(256);
     for (int p0 = 0; p0 < Pp; p0 += PG) {
         if (p0 == 0)
-            hipLaunchKernelGGL((k_mac<PG, false>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, p0, tchunk);
+            hipLaunchKernelGGL((k_mac<PG, false>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, irch_all, B, T, Tout, Tin, Pp, p0, tchunk);
         else
-            hipLaunchKernelGGL((k_mac<PG, true>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, p0, tchunk);
+            hipLaunchKernelGGL((k_mac<PG, true>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, irch_all, B, T, Tout, Tin, Pp, p0, tchunk);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_mac(int PG, const c32 *Z, c32 *W, const c32 *Hp, const c32 *wsplit, const int32_t *job_irch,
-                      int B, int T, int Tout, int Tin, int Pp, int njobs, int tchunk, hipStream_t s)
+                      int irch_all, int B, int T, int Tout, int Tin, int Pp, int njobs, int tchunk, hipStream_t s)
 {
     switch (PG) {
-    case 4: return launch_mac_t<4>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, tchunk, s);
-    case 8: return launch_mac_t<8>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, tchunk, s);
-    case 12: return launch_mac_t<12>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, tchunk, s);
-    case 16: return launch_mac_t<16>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, tchunk, s);
-    case 24: return launch_mac_t<24>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, tchunk, s);
+    case 4: return launch_mac_t<4>(Z, W, Hp, wsplit, job_irch, irch_all, B, T, Tout, Tin, Pp, njobs, tchunk, s);
+    case 8: return launch_mac_t<8>(Z, W, Hp, wsplit, job_irch, irch_all, B, T, Tout, Tin, Pp, njobs, tchunk, s);
+    case 12: return launch_mac_t<12>(Z, W, Hp, wsplit, job_irch, irch_all, B, T, Tout, Tin, Pp, njobs, tchunk, s);
+    case 16: return launch_mac_t<16>(Z, W, Hp, wsplit, job_irch, irch_all, B, T, Tout, Tin, Pp, njobs, tchunk, s);
+    case 24: return launch_mac_t<24>(Z, W, Hp, wsplit, job_irch, irch_all, B, T, Tout, Tin, Pp, njobs, tchunk, s);
     }
     return hipErrorInvalidValue;
 }
 
 template <int TB>
 static hipError_t launch_mac_gather_t(const c32 *Z, c32 *W, const c32 *Hp, const c32 *wsplit, const int32_t *job_irch,
-                                      int B, int T, int Tout, int Tin, int Pp, int njobs, hipStream_t s)
+                                      int irch_all, int B, int T, int Tout, int Tin, int Pp, int njobs, hipStream_t s)
 {
     const dim3 grid(B / 256, njobs, (Tout + TB - 1) / TB), block(256);
     if (Pp % 24 == 0)
-        hipLaunchKernelGGL((k_mac_gather<TB, 24>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp);
+        hipLaunchKernelGGL((k_mac_gather<TB, 24>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, irch_all, B, T, Tout, Tin, Pp);
     else if (Pp % 12 == 0)
-        hipLaunchKernelGGL((k_mac_gather<TB, 12>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp);
+        hipLaunchKernelGGL((k_mac_gather<TB, 12>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, irch_all, B, T, Tout, Tin, Pp);
     else if (Pp % 8 == 0)
-        hipLaunchKernelGGL((k_mac_gather<TB, 8>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp);
+        hipLaunchKernelGGL((k_mac_gather<TB, 8>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, irch_all, B, T, Tout, Tin, Pp);
     else
-        hipLaunchKernelGGL((k_mac_gather<TB, 4>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp);
+        hipLaunchKernelGGL((k_mac_gather<TB, 4>), grid, block, 0, s, Z, W, Hp, wsplit, job_irch, irch_all, B, T, Tout, Tin, Pp);
     return hipGetLastError();
 }
 
-hipError_t launch_mac_gather(const c32 *Z, c32 *W, const c32 *Hp, const c32 *wsplit, const int32_t *job_irch, int B,
-                             int T, int Tout, int Tin, int Pp, int njobs, hipStream_t s)
+hipError_t launch_mac_gather(const c32 *Z, c32 *W, const c32 *Hp, const c32 *wsplit, const int32_t *job_irch,
+                             int irch_all, int B, int T, int Tout, int Tin, int Pp, int njobs, hipStream_t s)
 {
     if (Tout <= 0) return hipSuccess;
     if (Tout > 65535 || njobs > 65535 || Pp % 4) return hipErrorInvalidValue;
     // more output blocks per workgroup share more loads; keep at least a workgroup per CU
     const int64_t wgs1 = (int64_t)(B / 256) * njobs * Tout;
-    if (wgs1 >= 4 * 256) return launch_mac_gather_t<4>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, s);
-    if (wgs1 >= 2 * 256) return launch_mac_gather_t<2>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, s);
-    return launch_mac_gather_t<1>(Z, W, Hp, wsplit, job_irch, B, T, Tout, Tin, Pp, njobs, s);
+    if (wgs1 >= 4 * 256) return launch_mac_gather_t<4>(Z, W, Hp, wsplit, job_irch, irch_all, B, T, Tout, Tin, Pp, njobs, s);
+    if (wgs1 >= 2 * 256) return launch_mac_gather_t<2>(Z, W, Hp, wsplit, job_irch, irch_all, B, T, Tout, Tin, Pp, njobs, s);
+    return launch_mac_gather_t<1>(Z, W, Hp, wsplit, job_irch, irch_all, B, T, Tout, Tin, Pp, njobs, s);
 }
 
 }  // namespace wp

@@ -32,10 +32,11 @@ hipError_t launch_fft_inv(int B, const c32 *W, int T, int njobs, float *out, int
 hipError_t launch_hpack(const c32 *Zir, c32 *Hc, const c32 *wbin, int B, int P, int Pp, int nch, hipStream_t s);
 // out[i] = lin[i] + lin[i+N] (second term while i+N < lin_len), i < out_len
 hipError_t launch_wrap_add(const float *lin, int64_t lin_len, int64_t N, float *out, int64_t out_len, hipStream_t s);
-hipError_t launch_mac_gather(const c32 *Z, c32 *W, const c32 *Hc, const c32 *wbin, const int32_t *job_irch, int B,
-                             int T, int Tout, int Tin, int Pp, int njobs, hipStream_t s);
+// job_irch: device table of the IR channel each job uses, or nullptr when every job uses channel irch_all
+hipError_t launch_mac_gather(const c32 *Z, c32 *W, const c32 *Hc, const c32 *wbin, const int32_t *job_irch,
+                             int irch_all, int B, int T, int Tout, int Tin, int Pp, int njobs, hipStream_t s);
 hipError_t launch_mac(int PG, const c32 *Z, c32 *W, const c32 *Hc, const c32 *wbin, const int32_t *job_irch,
-                      int B, int T, int Tout, int Tin, int Pp, int njobs, int tchunk, hipStream_t s);
+                      int irch_all, int B, int T, int Tout, int Tin, int Pp, int njobs, int tchunk, hipStream_t s);
 hipError_t launch_fft_inv_mix(int B, const c32 *W, int T, int nblocks, int nsrc, float *bus0, float *bus1, int64_t tl,
                               const double *vol, float *out, int64_t out_stride, int64_t out_len, const c32 *tables,
                               hipStream_t s);

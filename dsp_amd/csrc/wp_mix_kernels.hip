@@ -113,7 +113,9 @@ __device__ __noinline__ void fetch_general(const mix_desc &d, int64_t x0, int nf
         if (f >= nf) { q0.v[f] = q1.v[f] = 0.0f; continue; }
         const int64_t a = x0 + f + d.o;
         if (a < 0) {
-            if (a % d.asl == 0) { q0.v[f] = c0[0]; q1.v[f] = c1[0]; }
+            // a negative remainder is a negative index (NaN) unless it is -0: either a multiple of
+            // |sl|, or (|sl| > rl) a remainder that is itself a multiple of rl, e.g. -5 % 10 % 5
+            if ((a % d.asl) % d.rl == 0) { q0.v[f] = c0[0]; q1.v[f] = c1[0]; }
             else { q0.v[f] = q1.v[f] = nanv; }
             continue;
         }

@@ -17,7 +17,9 @@
  *     host memory.
  *   - Handles belong to the HIP device that was current when they were created.
  *     One handle must not be used from two threads at once; different handles
- *     may be.
+ *     may be.  A wp_ir / wp_conv / wp_reverb handle owns one workspace: its calls
+ *     may move from stream to stream (a call on a new stream waits, on the
+ *     device, for the handle's previous call), but are never concurrent.
  *   - Without a usable GPU every compute entry point fails with
  *     WP_ERR_NO_DEVICE.  There is no CPU fallback.
  */
@@ -203,7 +205,10 @@ wp_buf *wp_buf_create(int nch, int64_t frames);
 uint64_t wp_buf_id(const wp_buf *b);
 /* One more reference to a live buffer, or NULL if the id names none. */
 wp_buf *wp_buf_open(uint64_t id);
-/* Drop one reference; the memory is recycled when the last one goes. */
+/* Drop one reference; the memory is recycled when the last one goes: the next
+ * wp_buf_create of that size may hand it out again, zero-filled on the default
+ * stream.  Work queued on a NON-BLOCKING stream that still uses the buffer is not
+ * waited for: release a buffer only after such work has completed. */
 void wp_buf_release(wp_buf *b);
 /* which: 0 channels, 1 frames, 2 floats between channels, 3 device, 4 bytes. */
 int64_t wp_buf_info(const wp_buf *b, int which);
@@ -225,8 +230,21 @@ int wp_buf_fill(wp_buf *b, int ch, int64_t off, int64_t n, float value, void *st
 int64_t wp_ring_pos(int64_t needle, int64_t key, int64_t length);
 /* lib/ring-buffer.js:35-39: needle after a write at key 0. */
 int64_t wp_ring_advance(int64_t needle, int64_t length);
-/* src/loop-node.js:145-147 beatRate; :48-50 bufferSize = 4*beatRate. */
+/* -1 for an empty array (length <= 0), where the reference's wrap has no element to name. */
+/* src/loop-node.js:145-147 beatRate = Math.round(sampleRate*(60/bpm)); :48-50
+ * bufferSize = 4*beatRate.  -1 when the rate is not finite (bpm 0). */
 int64_t wp_beat_rate(double sample_rate, double bpm);
+/* src/loop-node.js:9-11 the bpm getter: parseFloat((60*(sampleRate/beatRate)).toFixed(6)). */
+double wp_bpm_from_beat_rate(double sample_rate, int64_t beat_rate);
+
+/* ---- tuning knobs for tests and measurements (no reference counterpart) ----- */
+/* Process-wide overrides of choices the library otherwise makes itself; value 0
+ * restores the library's choice.  They affect handles created afterwards. */
+#define WP_TUNE_PARTITION 0 /* partition size B: 1024, 2048, 4096 or 8192 */
+#define WP_TUNE_MAC_GROUP 1 /* partitions per multiply-accumulate pass: 4, 8, 12, 16, 24 */
+#define WP_TUNE_MAC_FORM 2  /* 1 streaming delay-line kernel, 2 small-batch gather kernel */
+#define WP_TUNE_POOL_MB 3   /* cap of the wp_buf recycling pool in MiB (default 2048; 0 disables it) */
+int wp_tune(int what, int64_t value);
 
 /* ---- synthetic inputs for tests and benchmarks (no reference counterpart) --- */
 /* out[i] = ((fmix32((start+i) ^ seed*0x9E3779B9) >> 8) - 2^23) / 2^23, on the device. */

@@ -69,7 +69,7 @@ def test_synth_noise_device_matches_oracle(torch, oracle):
 @pytest.mark.parametrize("L,M,njobs", [(5000, 1200, 6), (20000, 9000, 5), (70000, 30000, 3), (4096, 4096, 4), (100, 50000, 2),
                                         (3000, 110000, 2), (1, 1, 1), (700, 7400, 3), (20000, 210000, 2)])
 @pytest.mark.parametrize("mac", ["stream", "gather"])
-def test_batched_convolver_vs_oracle(torch, oracle, monkeypatch, L, M, njobs, mac):
+def test_batched_convolver_vs_oracle(torch, oracle, L, M, njobs, mac):
     """Ragged sizes (L, M not multiples of the partition), several jobs, IR channel map;
     (3000, 110000) needs 27 partitions = two accumulating MAC passes; (1, 1) is the
     smallest legal FFT; (20000, 210000) uses the 8192-point plan with two passes; (700, 7400) is the small-partition plan with 8 partitions.
@@ -77,11 +77,14 @@ def test_batched_convolver_vs_oracle(torch, oracle, monkeypatch, L, M, njobs, ma
     delay-line kernel and the small-batch gather kernel), which the library otherwise
     picks by batch size."""
     from dsp_amd import capi, device
-    monkeypatch.setenv("WPDSP_MAC", mac)
     irs = np.stack([oracle.synth_ir(M, 40), oracle.synth_ir(M, 41)])
     ir = device.DeviceIR(torch.from_numpy(irs).cuda(), L)
     job_ch = [(j * 3) % 2 for j in range(njobs)]
-    conv = device.BatchedConvolver(ir, job_ch)
+    capi.check(capi.lib().wp_tune(2, {"stream": 1, "gather": 2}[mac]), "wp_tune")  # WP_TUNE_MAC_FORM
+    try:
+        conv = device.BatchedConvolver(ir, job_ch)
+    finally:
+        capi.lib().wp_tune(2, 0)
     assert capi.lib().wp_conv_info(conv.handle, 5) == (1 if mac == "gather" else 0)
     x = np.stack([oracle.synth_noise(L, 50 + j) for j in range(njobs)])
     xd = torch.from_numpy(x).cuda()
@@ -345,15 +348,27 @@ def test_mix_full_size_properties(torch):
     assert torch.equal(mono[0], ref)
 
 
-@pytest.mark.parametrize("L,M,tracks,tl", [(9000, 5000, 5, 9000), (20000, 3000, 3, 23000), (4096, 4096, 2, 4097), (70000, 20000, 4, 65536)])
-def test_fused_reverb_mix_is_bit_identical_to_unfused(torch, L, M, tracks, tl):
+@pytest.mark.parametrize("L,M,tracks,tl,part", [(9000, 5000, 5, 9000, 0), (20000, 3000, 3, 23000, 0), (4096, 4096, 2, 4097, 0),
+                                                 (70000, 20000, 4, 65536, 0),
+                                                 (30000, 100000, 3, 30000, 0),    # 8192-point plan, 13 partitions
+                                                 (20000, 192000, 2, 50000, 0),    # 4 s IR: 8192-point plan, 24 partitions
+                                                 (3000, 2000, 3, 3000, 0),        # 1024-point plan
+                                                 (9000, 5000, 2, 9001, 2048)])    # 2048-point plan
+def test_fused_reverb_mix_is_bit_identical_to_unfused(torch, L, M, tracks, tl, part):
     """wp_conv_mix_run_dev == wp_conv_run_dev followed by wp_mix_dev, bit for bit
     (same samples, same f64 fold, same source order), for ragged sizes, a
-    non-zero starting bus and tl shorter/longer than L."""
-    from dsp_amd import device
+    non-zero starting bus and tl shorter/longer than L, with every partition size
+    the library has a plan for."""
+    from dsp_amd import capi, device
     njobs = 2 * tracks
     irs = torch.from_numpy(np.stack([device.synth_ir(M, 80), device.synth_ir(M, 81)])).cuda()
-    ir = device.DeviceIR(irs, L)
+    capi.check(capi.lib().wp_tune(0, part), "wp_tune")  # WP_TUNE_PARTITION
+    try:
+        ir = device.DeviceIR(irs, L)
+    finally:
+        capi.lib().wp_tune(0, 0)
+    want_B = part or (1024 if L + M <= 8192 else (8192 if M > 24 * 4096 else 4096))
+    assert ir.info(3) == want_B
     conv = device.BatchedConvolver(ir, [j % 2 for j in range(njobs)])
     x = torch.empty((njobs, L), dtype=torch.float32, device="cuda")
     for j in range(njobs):
@@ -387,6 +402,100 @@ def test_fused_reverb_mix_is_bit_identical_to_unfused(torch, L, M, tracks, tl):
     conv.run_mix(x, [bus_e[0], bus_e[1]], vol2)
     torch.cuda.synchronize()
     assert torch.equal(bus_d.view(torch.int32), bus_e.view(torch.int32))
+
+
+@pytest.mark.parametrize("L,M,tracks,per_track_ir", [(30000, 100000, 3, False), (20000, 192000, 2, False),
+                                                      (30000, 100000, 2, True), (3000, 2000, 3, False)])
+def test_fused_paths_vs_oracle_all_plans(torch, oracle, L, M, tracks, per_track_ir):
+    """The fused inverse-transform + mix kernels of the 8192-point plan (what a 4 s impulse
+    response selects: M = 192 000 gives 24 partitions of 8192) and of the 1024-point plan,
+    against the oracle: every job's go() result, the bus of wp_conv_run_mix_dev and the bus of
+    wp_conv_mix_run_dev, with a shared stereo IR and with an IR per job."""
+    from dsp_amd import device
+    njobs = 2 * tracks
+    nir = njobs if per_track_ir else 2
+    irs = np.stack([oracle.synth_ir(M, 600 + j) for j in range(nir)])
+    ir = device.DeviceIR(torch.from_numpy(irs).cuda(), L)
+    assert ir.info(3) == (8192 if M > 24 * 4096 else 1024)
+    job_ch = list(range(njobs)) if per_track_ir else [j % 2 for j in range(njobs)]
+    conv = device.BatchedConvolver(ir, job_ch)
+    x = np.stack([oracle.synth_noise(L, 700 + j) for j in range(njobs)])
+    xd = torch.from_numpy(x).cuda()
+    out = torch.full((njobs, L + M + 2), 9.0, dtype=torch.float32, device="cuda")
+    tl = L + M // 2
+    bus = torch.zeros((2, tl), dtype=torch.float32, device="cuda")
+    bus2 = torch.zeros((2, tl), dtype=torch.float32, device="cuda")
+    vol = [0.75 / (s + 1) for s in range(tracks)]
+    conv.run_and_mix(xd, out, [bus[0], bus[1]], vol)
+    conv.run_mix(xd, [bus2[0], bus2[1]], vol)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    kern = [oracle.fft_process_kernel(L, irs[c]) for c in range(nir)]
+    want = [oracle.fft_convolution(L, kern[job_ch[j]], M)(x[j]) for j in range(njobs)]
+    for j in range(njobs):
+        assert float(np.abs(got[j, :L + M].astype(np.float64) - want[j]).max()) <= TOL, j
+        assert (got[j, L + M:] == 9.0).all()
+    want_bus = [np.zeros(tl, np.float32), np.zeros(tl, np.float32)]
+    oracle.mix_buffers(want_bus, *[[[want[2 * s], want[2 * s + 1]], 1, vol[s], 0] for s in range(tracks)])
+    for ch in range(2):
+        assert float(np.abs(bus[ch].cpu().numpy().astype(np.float64) - want_bus[ch]).max()) <= TOL
+    assert torch.equal(bus.view(torch.int32), bus2.view(torch.int32))
+
+
+def test_mix_4096_aliased_stems_exact(torch):
+    """The master reduce at its full source count: 4096 stereo sources (all views of one
+    60 s stem, so the test holds 46 MB instead of 94 GB) with vol = 1/4096.  Samples with 11
+    significant bits make every partial sum j/4096 * x exact in f32, so the bus must equal the
+    stem bit for bit; a second pass over a ragged, unaligned range takes the general path."""
+    from dsp_amd import device
+    F, S = 2880000, 4096
+    stem = torch.empty((2, F), dtype=torch.float32, device="cuda")
+    device.synth_noise(stem[0], 21)
+    device.synth_noise(stem[1], 22)
+    stem = torch.round(stem * 1024) / 1024
+    bus = torch.zeros((2, F), dtype=torch.float32, device="cuda")
+    device.DeviceMix([{"ch": [stem[0], stem[1]], "vol": 1.0 / S} for _ in range(S)]).run([bus[0], bus[1]])
+    assert torch.equal(bus, stem)
+    # looping form: sl = 1000 frames of the stem repeated, offset 7: (x + 7) % 1000
+    n = 100003
+    bus = torch.zeros((2, n), dtype=torch.float32, device="cuda")
+    device.DeviceMix([{"ch": [stem[0], stem[1]], "rl": F, "sl": 1000, "o": 7, "vol": 1.0 / S} for _ in range(S)]).run([bus[0], bus[1]])
+    idx = (torch.arange(n, device="cuda") + 7) % 1000
+    assert torch.equal(bus, stem[:, idx])
+
+
+def test_single_job_calls_alternate_channels_across_streams(torch, oracle):
+    """wp_convolve_dev on one handle, alternating IR channels and alternating between two
+    non-blocking streams with no host synchronisation in between: the channel travels as a
+    launch argument and a call on a new stream waits for the handle's previous call, so every
+    result equals the one computed alone."""
+    from dsp_amd import capi
+    lib = capi.lib()
+    L, M = 50000, 30000
+    f32p = C.POINTER(C.c_float)
+    irs = [oracle.synth_ir(M, 5), oracle.synth_ir(M, 6)]
+    h = capi.check_handle(lib.wp_ir_create((f32p * 2)(*[a.ctypes.data_as(f32p) for a in irs]), 2, M, L), "wp_ir_create")
+    xs = [torch.from_numpy(oracle.synth_noise(L, 30 + i)).cuda() for i in range(2)]
+    ref = []
+    for ch in range(2):
+        o = torch.empty(L + M, dtype=torch.float32, device="cuda")
+        capi.check(lib.wp_convolve_dev(h, ch, C.c_void_p(xs[ch].data_ptr()), L, C.c_void_p(o.data_ptr()), None))
+        torch.cuda.synchronize()
+        ref.append(o)
+        want = oracle.fft_convolution(L, oracle.fft_process_kernel(L, irs[ch]), M)(xs[ch].cpu().numpy())
+        assert float(np.abs(o.cpu().numpy().astype(np.float64) - want).max()) <= TOL
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.empty(L + M, dtype=torch.float32, device="cuda") for _ in range(12)]
+    torch.cuda.synchronize()
+    for i in range(12):
+        ch = i % 2
+        st = streams[(i // 3) % 2]
+        capi.check(lib.wp_convolve_dev(h, ch, C.c_void_p(xs[ch].data_ptr()), L, C.c_void_p(outs[i].data_ptr()),
+                                       C.c_void_p(st.cuda_stream)))
+    torch.cuda.synchronize()
+    for i in range(12):
+        assert torch.equal(outs[i].view(torch.int32), ref[i % 2].view(torch.int32)), i
+    lib.wp_ir_destroy(h)
 
 
 def test_reverb_tail_roundtrip_and_error_paths(torch, oracle):
