@@ -44,6 +44,29 @@ static int fail(int code, const char *fmt, ...)
 static std::mutex g_mu;
 static int g_ndev = -2;  // -2: not probed
 
+// ---------------------------------------------------------------------------
+// Workspace of wp_convolve_dev_noalloc: the block spectra Z and W of one channel-job, in a
+// device array that belongs to the code object, so that the entry point never allocates.
+// Every GPU that loads the library holds its own copy at its own address.  The name below
+// is a host-side stand-in: host code only ever uses the per-device address that
+// hipGetSymbolAddress returns (g_static_ws), for kernel arguments and memsets alike.
+static __device__ __align__(256) unsigned char g_static_ws_array[WP_NOALLOC_WORKSPACE_BYTES];
+static std::map<int, void *> g_static_ws;  // device -> address of its copy; guarded by g_mu
+
+static int static_ws_locked(int dev, void **out)  // the caller holds g_mu and has `dev` current
+{
+    auto it = g_static_ws.find(dev);
+    if (it == g_static_ws.end()) {
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_ws_array));
+        if (e != hipSuccess || !p)
+            return fail(WP_ERR_HIP, "hipGetSymbolAddress(static workspace) failed on device %d: %s", dev, hipGetErrorString(e));
+        it = g_static_ws.emplace(dev, p).first;
+    }
+    *out = it->second;
+    return WP_OK;
+}
+
 extern "C" int wp_init(void)
 {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -59,6 +82,13 @@ extern "C" int wp_init(void)
     if (g_ndev < 0) {
         if (g_err.empty()) g_err = "no HIP device";
         return WP_ERR_NO_DEVICE;
+    }
+    // the current device's static workspace address, once (other devices: on their first
+    // wp_init or wp_convolve_dev_noalloc call with that device current)
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && !g_static_ws.count(dev)) {
+        void *p = nullptr;
+        if (int rc = static_ws_locked(dev, &p)) return rc;
     }
     return g_ndev;
 }
@@ -851,6 +881,45 @@ extern "C" int wp_convolve_dev(wp_ir *ir, int ch, const float *in_dev, int64_t i
     if (input_wraps(ir, in_len)) return convolve_wrapped(ir, ch, in_dev, in_len, out_dev, (hipStream_t)stream);
     if (int rc = single_plan(ir, ch)) return rc;
     return wp_conv_run_dev(ir->single, in_dev, 0, in_len, out_dev, 0, nullptr, 0, 0, stream);
+}
+
+// wp_convolve_dev with the block spectra in the library's static device workspace: no
+// allocation of any kind happens in this call (callers under stream capture, or harnesses that
+// forbid hipMalloc).  Same kernels, same geometry, hence the same bits as wp_convolve_dev.
+extern "C" int wp_convolve_dev_noalloc(wp_ir *ir, int ch, const float *in_dev, int64_t in_len, float *out_dev,
+                                       void *stream)
+{
+    if (int rc = need_device()) return rc;
+    if (!ir || !out_dev || (!in_dev && in_len > 0)) return fail(WP_ERR_INVALID, "wp_convolve_dev_noalloc: null argument");
+    if (ch < 0 || ch >= ir->nch) return fail(WP_ERR_INVALID, "wp_convolve_dev_noalloc: IR channel %d of %d", ch, ir->nch);
+    if (int rc = check_in_len(ir, in_len)) return rc;  // inputs that wrap in the reference's FFT: wp_convolve_dev
+    wp_conv plan;
+    plan_geometry(&plan, ir, 1, ir->L + ir->M);
+    const size_t sbytes = sizeof(c32) * (size_t)plan.T * ir->B;
+    if (2 * sbytes > (size_t)WP_NOALLOC_WORKSPACE_BYTES)
+        return fail(WP_ERR_RANGE,
+                    "wp_convolve_dev_noalloc: L+M = %lld needs %zu bytes of block spectra, the static workspace holds %lld "
+                    "(results up to %lld samples); use wp_convolve_dev",
+                    (long long)(ir->L + ir->M), 2 * sbytes, (long long)WP_NOALLOC_WORKSPACE_BYTES,
+                    (long long)(WP_NOALLOC_WORKSPACE_BYTES / (2 * sizeof(c32)) - ir->B + 1));
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev != ir->dev) return fail(WP_ERR_INVALID, "wp_convolve_dev_noalloc: the IR handle belongs to device %d, device %d is current", ir->dev, dev);
+    void *ws = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (int rc = static_ws_locked(dev, &ws)) return rc;
+    }
+    // Z and W are rewritten from scratch by every call (each block the inverse transform reads
+    // has been stored by this call's MAC, each block the MAC reads by this call's forward
+    // transform), so nothing of the previous call's contents needs clearing.
+    plan.Z = reinterpret_cast<c32 *>(ws);
+    plan.W = reinterpret_cast<c32 *>(static_cast<unsigned char *>(ws) + WP_NOALLOC_WORKSPACE_BYTES / 2);
+    plan.irch_all = ch;
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = conv_front(&plan, in_dev, 0, in_len, plan.T, s)) return rc;
+    HIPCHK(launch_fft_inv(ir->B, plan.W, plan.T, 1, out_dev, 0, plan.out_len, nullptr, 0, 0, ir->tables, s));
+    return WP_OK;
 }
 
 extern "C" int wp_convolve(wp_ir *ir, int ch, const float *in, int64_t in_len, float *out)

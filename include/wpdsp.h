@@ -45,7 +45,9 @@ typedef struct wp_conv wp_conv;     /* a batch of channel-jobs convolving with o
 typedef struct wp_reverb wp_reverb; /* wp_conv + carried tail per job (block reverb) */
 typedef struct wp_buf wp_buf;       /* device-resident sample buffer: channels x frames of f32 */
 
-/* Number of visible HIP devices, or WP_ERR_NO_DEVICE.  Idempotent, thread-safe. */
+/* Number of visible HIP devices, or WP_ERR_NO_DEVICE.  Idempotent, thread-safe.
+ * Also looks up, for the HIP device current at the call, the address of the
+ * library's static workspace (see wp_convolve_dev_noalloc). */
 int wp_init(void);
 /* Message for the last failure on the calling thread ("" if none). */
 const char *wp_last_error(void);
@@ -83,6 +85,23 @@ int64_t wp_ir_info(const wp_ir *ir, int which);
 int wp_convolve(wp_ir *ir, int ch, const float *in, int64_t in_len, float *out);
 /* The same with input and result in device memory (in_len floats in, L+M out). */
 int wp_convolve_dev(wp_ir *ir, int ch, const float *in_dev, int64_t in_len, float *out_dev, void *stream);
+
+/* No counterpart in the reference.  wp_convolve_dev for callers that cannot
+ * allocate device memory when they call (code under HIP stream capture, tight
+ * serving loops, harnesses that forbid hipMalloc): the block spectra live in a
+ * static device array of WP_NOALLOC_WORKSPACE_BYTES that the library's code object
+ * carries (one copy per GPU, held until the process ends), and the call makes no
+ * hipMalloc/hipFree or other allocating call.  Same kernels and geometry as
+ * wp_convolve_dev, so the result is bit-identical to it.  Limits: the result
+ * length L+M must satisfy ceil((L+M)/B)*B <= WP_NOALLOC_WORKSPACE_BYTES/16 complex
+ * points (B = wp_ir_info(ir, 3); with B = 4096 that is L+M <= 524288 samples, 10.9 s
+ * at 48 kHz), else WP_ERR_RANGE; inputs that wrap in the reference's FFT are
+ * WP_ERR_UNSUPPORTED (use wp_convolve_dev).  Call wp_init() (or this function once)
+ * on the device before capturing.  All calls on one GPU share the workspace: calls
+ * that overlap in time on one GPU (two streams, two threads) race; calls on one
+ * stream are ordered and safe. */
+#define WP_NOALLOC_WORKSPACE_BYTES (8 * 1024 * 1024)
+int wp_convolve_dev_noalloc(wp_ir *ir, int ch, const float *in_dev, int64_t in_len, float *out_dev, void *stream);
 
 /* Batched: njobs independent go() calls sharing one launch sequence.  job_ch[j]
  * (host array) is the IR channel job j uses. */
