@@ -71,6 +71,13 @@ PROTOTYPES = {
     "wp_mix_sl": (C.c_int32, [C.c_int64, C.c_double]),
     "wp_mix": (C.c_int, [C.POINTER(f32p), C.c_int, C.c_int64, C.POINTER(WpSrc), C.c_int64]),
     "wp_mix_dev": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "wp_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "wp_comm_create": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
+    "wp_comm_destroy": (None, [C.c_void_p]),
+    "wp_comm_info": (C.c_int64, [C.c_void_p, C.c_int]),
+    "wp_comm_library": (C.c_char_p, []),
+    "wp_bus_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "wp_bus_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "wp_buf_create": (C.c_void_p, [C.c_int, C.c_int64]),
     "wp_buf_id": (C.c_uint64, [C.c_void_p]),
     "wp_buf_open": (C.c_void_p, [C.c_uint64]),

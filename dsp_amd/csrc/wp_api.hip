@@ -34,6 +34,13 @@ static int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// for the other translation units of the library (not exported)
+extern "C" __attribute__((visibility("hidden"))) int wp_fail_message(int code, const char *msg)
+{
+    g_err = msg ? msg : "";
+    return code;
+}
+
 #define HIPCHK(expr)                                                                       \
     do {                                                                                   \
         hipError_t e__ = (expr);                                                           \

@@ -182,10 +182,73 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def reduce_master_bus(bus, dist, dst=0):
+class Comm:
+    """One rank of the track-sharded render: wp_comm (an RCCL communicator created through the
+    C ABI).  `rendezvous` carries the 128-byte id from rank 0 to the others: a callable
+    bytes -> bytes that returns rank 0's argument on every rank (e.g. a gloo broadcast)."""
+
+    def __init__(self, rank, world, rendezvous=None):
+        capi.init()
+        L = capi.lib()
+        idb = (C.c_ubyte * 128)()
+        if rank == 0:
+            capi.check(L.wp_comm_unique_id(idb), "wp_comm_unique_id")
+        raw = bytes(idb)
+        if world > 1:
+            if rendezvous is None:
+                raise ValueError("more than one rank needs a rendezvous callable to pass the id")
+            raw = rendezvous(raw)
+        idb = (C.c_ubyte * 128).from_buffer_copy(raw)
+        self.rank, self.world = rank, world
+        self.handle = capi.check_handle(L.wp_comm_create(idb, world, rank), "wp_comm_create")
+
+    @property
+    def library(self):
+        return capi.lib().wp_comm_library().decode()
+
+    def reduce(self, bus, dst=0, out=None, stream=None):
+        """Sum the rank-local buses onto rank `dst` (in place unless `out` is given), one message."""
+        import torch
+        assert bus.is_cuda and bus.dtype == torch.float32 and bus.is_contiguous()
+        recv = bus if out is None else out
+        sp = C.c_void_p(stream.cuda_stream) if stream is not None else _stream_ptr(torch)
+        capi.check(capi.lib().wp_bus_reduce(self.handle, C.c_void_p(bus.data_ptr()), C.c_void_p(recv.data_ptr()),
+                                            bus.numel(), dst, sp), "wp_bus_reduce")
+        return recv
+
+    def allreduce(self, bus, out=None, stream=None):
+        import torch
+        assert bus.is_cuda and bus.dtype == torch.float32 and bus.is_contiguous()
+        recv = bus if out is None else out
+        sp = C.c_void_p(stream.cuda_stream) if stream is not None else _stream_ptr(torch)
+        capi.check(capi.lib().wp_bus_allreduce(self.handle, C.c_void_p(bus.data_ptr()), C.c_void_p(recv.data_ptr()),
+                                               bus.numel(), sp), "wp_bus_allreduce")
+        return recv
+
+    def close(self):
+        if getattr(self, "handle", None):
+            capi.lib().wp_comm_destroy(self.handle)
+            self.handle = None
+
+
+def gloo_rendezvous(dist, src=0):
+    """bytes -> bytes broadcast over an initialised torch.distributed group with CPU tensors."""
+    def bcast(raw):
+        import torch
+        t = torch.tensor(list(raw), dtype=torch.uint8)
+        dist.broadcast(t, src=src)
+        return bytes(t.tolist())
+    return bcast
+
+
+def reduce_master_bus(bus, dist, dst=0, comm=None):
     """The path's one exchange step: sum the rank-local partial buses onto rank
-    `dst` (RCCL over xGMI on GPUs, gloo on CPU tensors).  `bus` is a single
-    tensor [channels, frames]; one message per call."""
+    `dst`.  With `comm` (a Comm) the reduce is wp_bus_reduce, RCCL called through the C ABI;
+    otherwise torch.distributed carries it (gloo for CPU tensors in the CPU rehearsal of the
+    multi-rank flow).  `bus` is a single tensor [channels, frames]; one message per call."""
+    if comm is not None:
+        comm.reduce(bus, dst=dst)
+        return bus
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         if bus.is_cuda and dist.get_backend() == "gloo":  # rehearsal without RCCL: stage through the host
             host = bus.cpu()

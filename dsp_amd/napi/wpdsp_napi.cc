@@ -751,6 +751,74 @@ static napi_value js_beat_rate(napi_env env, napi_callback_info info)
     return num(env, (double)wp_beat_rate(sr, bpm));
 }
 
+static napi_value js_bpm_from_beat_rate(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    double sr;
+    int64_t br;
+    if (napi_get_value_double(env, argv[0], &sr) != napi_ok || !get_i64(env, argv[1], &br)) return throw_wp(env, WP_ERR_INVALID);
+    return num(env, wp_bpm_from_beat_rate(sr, br));
+}
+
+// ---- multi-GPU: one process per GPU, the partial master buses summed by RCCL ------
+static void comm_finalize(napi_env, void *p, void *) { wp_comm_destroy((wp_comm *)p); }
+
+// commUniqueId() -> Uint8Array(128), made by rank 0 and handed to the other ranks by the host
+static napi_value js_comm_unique_id(napi_env env, napi_callback_info)
+{
+    napi_value ab, ta;
+    void *p = NULL;
+    NAPI_CALL(env, napi_create_arraybuffer(env, WP_COMM_ID_BYTES, &p, &ab));
+    const int rc = wp_comm_unique_id((unsigned char *)p);
+    if (rc) return throw_wp(env, rc);
+    NAPI_CALL(env, napi_create_typedarray(env, napi_uint8_array, WP_COMM_ID_BYTES, ab, 0, &ta));
+    return ta;
+}
+
+// commCreate(idUint8Array, nranks, rank) -> handle (returns when every rank has joined)
+static napi_value js_comm_create(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    bool is = false;
+    napi_typedarray_type type;
+    size_t length = 0, byte_offset = 0;
+    void *data = NULL;
+    napi_value ab;
+    int64_t nranks, rank;
+    if (napi_is_typedarray(env, argv[0], &is) != napi_ok || !is ||
+        napi_get_typedarray_info(env, argv[0], &type, &length, &data, &ab, &byte_offset) != napi_ok ||
+        type != napi_uint8_array || length != WP_COMM_ID_BYTES || !get_i64(env, argv[1], &nranks) ||
+        !get_i64(env, argv[2], &rank)) {
+        napi_throw_type_error(env, NULL, "commCreate(Uint8Array(128) id, nranks, rank)");
+        return NULL;
+    }
+    wp_comm *c = wp_comm_create((const unsigned char *)data, (int)nranks, (int)rank);
+    if (!c) return throw_wp(env, WP_ERR_HIP);
+    return wrap_ptr(env, c, comm_finalize);
+}
+
+// busReduce(comm, bufferHandle, root, all): every channel of a device buffer (one message) summed over
+// the ranks, onto `root` in place, or onto every rank when `all` is true.  Returns when the result is there.
+static napi_value js_bus_reduce(napi_env env, napi_callback_info info)
+{
+    ARGS(4);
+    wp_comm *c = unwrap<wp_comm>(env, argv[0]);
+    if (!c) return NULL;
+    wp_buf *b = unwrap<wp_buf>(env, argv[1]);
+    if (!b) return NULL;
+    int64_t root;
+    bool all = false;
+    if (!get_i64(env, argv[2], &root) || napi_get_value_bool(env, argv[3], &all) != napi_ok) return throw_wp(env, WP_ERR_INVALID);
+    float *p = wp_buf_channel(b, 0);
+    const int64_t count = wp_buf_info(b, 0) * wp_buf_info(b, 2);  // channels x floats between channels (padding is zero)
+    int rc = all ? wp_bus_allreduce(c, p, p, count, NULL) : wp_bus_reduce(c, p, p, count, (int)root, NULL);
+    if (rc) return throw_wp(env, rc);
+    float probe;  // a blocking read on the default stream: the reduce has completed when it returns
+    rc = wp_buf_info(b, 1) > 0 ? wp_buf_read(b, 0, 0, &probe, 1) : 0;
+    if (rc) return throw_wp(env, rc);
+    return NULL;
+}
+
 NAPI_MODULE_INIT()
 {
     const napi_property_descriptor props[] = {
@@ -777,6 +845,10 @@ NAPI_MODULE_INIT()
         {"mixDev", NULL, js_mix_dev, NULL, NULL, NULL, napi_enumerable, NULL},
         {"ringPos", NULL, js_ring_pos, NULL, NULL, NULL, napi_enumerable, NULL},
         {"beatRate", NULL, js_beat_rate, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"bpmFromBeatRate", NULL, js_bpm_from_beat_rate, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"commUniqueId", NULL, js_comm_unique_id, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"commCreate", NULL, js_comm_create, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"busReduce", NULL, js_bus_reduce, NULL, NULL, NULL, napi_enumerable, NULL},
     };
     if (napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props) != napi_ok) return NULL;
     return exports;

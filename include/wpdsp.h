@@ -44,6 +44,7 @@ typedef struct wp_ir wp_ir;         /* device-resident partitioned spectra of an
 typedef struct wp_conv wp_conv;     /* a batch of channel-jobs convolving with one wp_ir */
 typedef struct wp_reverb wp_reverb; /* wp_conv + carried tail per job (block reverb) */
 typedef struct wp_buf wp_buf;       /* device-resident sample buffer: channels x frames of f32 */
+typedef struct wp_comm wp_comm;     /* one rank of a multi-GPU render: an RCCL communicator */
 
 /* Number of visible HIP devices, or WP_ERR_NO_DEVICE.  Idempotent, thread-safe.
  * Also looks up, for the HIP device current at the call, the address of the
@@ -210,6 +211,36 @@ int wp_mix(float *const *tgt, int tch, int64_t tl, const wp_src *srcs, int64_t n
  * arrays, reads an aliased source as it was before the call). */
 int wp_mix_dev(float *const *tgt_dev, int tch, int64_t tl, const wp_src *srcs, int64_t nsrc, int srcs_on_device,
                void *stream);
+
+/* ---- multi-GPU: the master bus of a track-sharded render ---------------------- */
+/* Tracks are independent buffers in the reference (each c.src / c.render renders
+ * into its own, src/context.js:145-162) and the only coupling is their sum into
+ * the master buffer (src/mix-buffers.js:1-73, src/mix.js:15-27).  With one process
+ * per GPU, rank r reverbs and mixes its share of the tracks into a rank-local
+ * partial bus; ONE reduce combines the partial buses.  That reduce is RCCL over
+ * xGMI; RCCL is opened (dlopen) at the first wp_comm_* call, from the directory of
+ * the HIP runtime the process uses.  The cross-rank sum adds the partial buses in
+ * RCCL's order, so the N-rank bus matches the sequential mix to rounding (<= 1e-5
+ * of full scale for buses within +-1), not bit for bit; one rank returns its bus
+ * unchanged. */
+#define WP_COMM_ID_BYTES 128
+/* Rank 0 makes the id (ncclGetUniqueId) and hands its bytes to the other ranks by
+ * whatever channel the host has (a file, a socket, a worker message). */
+int wp_comm_unique_id(unsigned char *id_out /* WP_COMM_ID_BYTES */);
+/* Every rank, with its GPU current (hipSetDevice): joins the communicator; returns
+ * when all nranks ranks have.  NULL on failure. */
+wp_comm *wp_comm_create(const unsigned char *id, int nranks, int rank);
+void wp_comm_destroy(wp_comm *c);
+/* which: 0 ranks, 1 this rank, 2 device. */
+int64_t wp_comm_info(const wp_comm *c, int which);
+/* Path of the RCCL library in use ("" before the first wp_comm_* call). */
+const char *wp_comm_library(void);
+/* recv[i] = sum over ranks of send[i], i < count, on rank `root` (recv_dev may be
+ * NULL elsewhere and may equal send_dev); asynchronous on `stream`.  A stereo bus
+ * of F frames stored as [2][F] is one call with count = 2*F. */
+int wp_bus_reduce(wp_comm *c, const float *send_dev, float *recv_dev, int64_t count, int root, void *stream);
+/* The same with the sum delivered to every rank. */
+int wp_bus_allreduce(wp_comm *c, const float *send_dev, float *recv_dev, int64_t count, void *stream);
 
 /* ---- device-resident sample buffers ---------------------------------------- */
 /* The reference keeps samples in arrays of Float32Array channels over

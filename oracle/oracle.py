@@ -361,3 +361,12 @@ def beat_rate(sample_rate, bpm):
 def buffer_size(sample_rate, bpm):
     """src/loop-node.js:48-50"""
     return beat_rate(sample_rate, bpm) * 4
+
+
+def bpm_from_beat_rate(sample_rate, beat_rate_):
+    """src/loop-node.js:9-16 the bpm getter: parseFloat((60 * (sampleRate / beatRate)).toFixed(6)).
+    Number.prototype.toFixed rounds the exact binary value to six decimals, ties to the larger
+    magnitude; Decimal(float) is exact, so ROUND_HALF_UP reproduces it."""
+    from decimal import ROUND_HALF_UP, Decimal
+    x = 60.0 * (float(sample_rate) / float(beat_rate_))
+    return float(Decimal(x).quantize(Decimal("0.000001"), rounding=ROUND_HALF_UP))

@@ -10,6 +10,7 @@ import impulseReverb from '../../dsp_amd/js/lib/impulse-reverb.js'
 import impulseReverbStereo from '../../dsp_amd/js/lib/impulse-reverb-stereo.js'
 import mixBuffers from '../../dsp_amd/js/src/mix-buffers.js'
 import { DeviceBuffer, DeviceChannel, isDeviceChannel } from '../../dsp_amd/js/src/device-buffer.js'
+import { uniqueId, createComm, reduceBus } from '../../dsp_amd/js/src/bus-reduce.js'
 
 let checks = 0
 const fail = msg => { throw new Error(msg) }
@@ -143,6 +144,12 @@ const main = async () => {
     mixBuffers(bus, ...stemsDev.map((b, i) => [b, 1, 1 / (i + 1), 0]))
     mixBuffers(want, ...stemsDev.map((_, i) => [renderStem(frames, i), 1, 1 / (i + 1), 0]))
     want.forEach((a, c) => sameBits(bus[c], a, 'bus from worker-rendered device stems ch' + c))
+    // the multi-GPU exchange step with the one rank this box has: RCCL through the addon returns the bus unchanged
+    const comm = createComm(uniqueId(), 1, 0)
+    reduceBus(comm, bus)
+    want.forEach((a, c) => sameBits(bus[c], a, 'bus after a one-rank reduce ch' + c))
+    reduceBus(comm, bus, { all: true })
+    want.forEach((a, c) => sameBits(bus[c], a, 'bus after a one-rank all-reduce ch' + c))
   }
   console.log('ok device ' + checks + ' checks')
 }

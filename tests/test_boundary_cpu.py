@@ -45,6 +45,19 @@ def test_integer_helpers_match_reference_vectors():
     g6 = load_golden("g6_ring_and_loop.json")
     for b in g6["beat"]:
         assert lib.wp_beat_rate(b["sr"], b["bpm"]) == b["beat_rate"]
+    # the bpm getter (src/loop-node.js:9-16), including toFixed(6) ties
+    for b in g6["beat"]:
+        assert lib.wp_bpm_from_beat_rate(b["sr"], b["beat_rate"]) == b["bpm_back"]
+    g10 = load_golden("g10_loop_bpm.json")
+    for r in g10["rows"]:
+        br0 = lib.wp_beat_rate(r["sr"], r["bpm"])
+        back = lib.wp_bpm_from_beat_rate(r["sr"], br0)
+        assert back == r["bpm_back"], r
+        assert lib.wp_beat_rate(r["sr"], back) == r["beat_rate"]
+    for t in g10["ties"]:
+        assert lib.wp_bpm_from_beat_rate(t["sr"], t["beat_rate"]) == t["bpm_back"], t
+    # no element / no block length where the reference yields NaN or Infinity
+    assert lib.wp_ring_pos(0, 3, 0) == -1 and lib.wp_ring_advance(0, 0) == -1 and lib.wp_beat_rate(48000, 0) == -1
     # ring buffer replay (test/ring-buffer.js:14-39)
     buf, needle = [0.0] * 3, 0
     for st in g6["ring3"]:

@@ -226,3 +226,82 @@ def test_convolution_properties_full_size(wp, oracle):
     a, b = oracle.synth_noise(L, 31), oracle.synth_noise(L, 32)
     ya, yb, yab = go(a), go(b), go((a * 0.5 + b * 0.25).astype(np.float32))
     _close(yab, 0.5 * ya.astype(np.float64) + 0.25 * yb, "linearity", tol=2e-6)
+
+
+def test_g7_render_jobs_with_4s_impulse_responses(wp, oracle):
+    """Two channel-jobs of the 2048-track render (L = 2 880 000, M = 192 000: the 8192-point
+    plan, 24 partitions, one impulse response per job) through the batched one-pass entry
+    point, against what the reference JavaScript produced for them."""
+    import torch
+    from dsp_amd import device
+    g = load_golden("g7_c5_jobs.json")
+    L, M = g["L"], g["M"]
+    jobs = g["jobs"]
+    irs = torch.from_numpy(np.stack([device.synth_ir(M, j["seed_ir"]) for j in jobs])).cuda()
+    ir = device.DeviceIR(irs, L)
+    assert ir.info(3) == 8192 and ir.info(4) == 24
+    conv = device.BatchedConvolver(ir, [0, 1])
+    x = torch.empty((2, L), dtype=torch.float32, device="cuda")
+    for i, j in enumerate(jobs):
+        device.synth_noise(x[i], j["seed_x"])
+    out = torch.empty((2, L + M), dtype=torch.float32, device="cuda")
+    bus = torch.zeros((2, L), dtype=torch.float32, device="cuda")
+    conv.run_and_mix(x, out, [bus[0], bus[1]], [0.5])
+    got = out.cpu().numpy()
+    for i, j in enumerate(jobs):
+        y = got[i]
+        _close(y[:64], from_bits(j["head"]), "head")
+        _close(y[-64:], from_bits(j["tail"]), "tail")
+        _close(y[j["mid"]["at"]:j["mid"]["at"] + 256], from_bits(j["mid"]["data"]), "mid")
+        err = _close(y[::j["stride"]], from_bits(j["samples"]), "strided")
+        print("4 s IR job %d max abs err vs reference: %.3e" % (i, err))
+    # the bus is the f64 fold of the two written results with vol = 0.5 (mix-buffers.js:49-52)
+    hb = bus.cpu().numpy()
+    for ch in range(2):
+        want = (np.float64(0) + got[ch, :L].astype(np.float64) * 0.5).astype(np.float32)
+        assert np.array_equal(hb[ch], want)
+
+
+def test_g8_mix_negative_offsets_bit_exact(wp):
+    g = load_golden("g8_mix_negative_offsets.json")
+    for case in g["cases"]:
+        target = [from_bits(b).copy() for b in case["target_in"]]
+        wp.mix.mix_buffers(target, *_sources(case))
+        for ch, exp in enumerate(case["target_out"]):
+            assert_bits_equal(target[ch], exp, case["name"] + " ch%d" % ch)
+
+
+def test_g9_render_buffer_conventions_host_and_device(wp):
+    """The buffer conventions of src/render.js:27-48 reproduced by the mix kernel, with host
+    arrays (wp_mix) and with device-resident buffers (wp_buf + wp_mix_dev, the route a bar
+    takes when it stays on the GPU)."""
+    import ctypes as C
+    from test_oracle_golden import render_conventions_via_mix
+    g = load_golden("g9_render_conventions.json")
+    for case, target in render_conventions_via_mix(wp.mix.mix_buffers, g):
+        for ch, exp in enumerate(case["out"]):
+            assert_bits_equal(target[ch], exp, "host: %s fn into %d channel(s), ch%d" % (case["fn"], case["channels"], ch))
+    lib, capi = wp.capi.lib(), wp.capi
+    n = g["frames"]
+    f32p = C.POINTER(C.c_float)
+    chans = {"mono": [from_bits(g["mono"])], "stereo": [from_bits(g["left"]), from_bits(g["right"])]}
+    for case in g["cases"]:
+        src = chans[case["fn"]]
+        sb = capi.check_handle(lib.wp_buf_create(len(src), n), "wp_buf_create")
+        tb = capi.check_handle(lib.wp_buf_create(case["channels"], n), "wp_buf_create")
+        try:
+            for c, a in enumerate(src):
+                capi.check(lib.wp_buf_write(sb, c, 0, a.ctypes.data_as(f32p), n), "wp_buf_write")
+            d = capi.WpSrc()
+            for c in range(len(src)):
+                d.ch[c] = lib.wp_buf_channel(sb, c)
+            d.nch, d.rl, d.sl, d.vol, d.o = len(src), n, n, 1.0, 0
+            tgt = (C.c_void_p * case["channels"])(*[lib.wp_buf_channel(tb, c) for c in range(case["channels"])])
+            capi.check(lib.wp_mix_dev(tgt, case["channels"], n, C.byref(d), 1, 0, None), "wp_mix_dev")
+            for ch, exp in enumerate(case["out"]):
+                got = np.empty(n, np.float32)
+                capi.check(lib.wp_buf_read(tb, ch, 0, got.ctypes.data_as(f32p), n), "wp_buf_read")
+                assert_bits_equal(got, exp, "device: %s fn into %d channel(s), ch%d" % (case["fn"], case["channels"], ch))
+        finally:
+            lib.wp_buf_release(sb)
+            lib.wp_buf_release(tb)

@@ -191,3 +191,83 @@ def test_g6_ring_buffer_and_loop_integers(oracle):
         assert oracle.buffer_size(b["sr"], b["bpm"]) == b["buffer_size"]
     # the configuration the stereo-reverb benchmark is quoted on: 48 kHz, 120 BPM
     assert oracle.beat_rate(48000, 120) == 24000 and oracle.buffer_size(48000, 120) == 96000
+
+
+def test_g7_render_jobs_with_4s_impulse_responses(oracle):
+    """Channel-jobs of the 2048-track render (L = 2 880 000, M = 192 000, an IR per job)."""
+    g = load_golden("g7_c5_jobs.json")
+    for job in g["jobs"]:
+        ir = oracle.synth_ir(g["M"], job["seed_ir"])
+        x = oracle.synth_noise(g["L"], job["seed_x"])
+        k = oracle.fft_process_kernel(g["L"], ir)
+        assert len(k) == job["kernel_len"]
+        y = oracle.fft_convolution(g["L"], k, g["M"])(x)
+        assert len(y) == job["out_len"] == g["L"] + g["M"]
+        assert_bits_equal(y[:64], job["head"], "head")
+        assert_bits_equal(y[-64:], job["tail"], "tail")
+        assert_bits_equal(y[job["mid"]["at"]:job["mid"]["at"] + 256], job["mid"]["data"], "mid")
+        assert_bits_equal(y[::job["stride"]], job["samples"], "strided")
+
+
+def test_g8_mix_negative_offsets(oracle):
+    g = load_golden("g8_mix_negative_offsets.json")
+    assert len(g["cases"]) == 20
+    for case in g["cases"]:
+        target = [from_bits(b).copy() for b in case["target_in"]]
+        oracle.mix_buffers(target, *_sources(case))
+        for ch, exp in enumerate(case["target_out"]):
+            assert_bits_equal(target[ch], exp, case["name"] + " ch%d" % ch)
+    # the -0 index is hit: some outputs of the first case are finite beside NaNs
+    first = from_bits(g["cases"][0]["target_out"][0])
+    assert np.isnan(first).any() and np.isfinite(first).any()
+
+
+def render_conventions_via_mix(mix_buffers, g):
+    """src/render.js:27-48 as mixBuffers arithmetic on a zeroed buffer: a mono function's
+    samples into 2 channels are (s/2)*1 on both (render: /numOfChannels, then buffer[1].set(buffer[0])),
+    a stereo function's into 1 channel ((l+r)/2)*1, equal layouts are copies."""
+    n = g["frames"]
+    mono, left, right = from_bits(g["mono"]), from_bits(g["left"]), from_bits(g["right"])
+    out = []
+    for case in g["cases"]:
+        target = [np.zeros(n, np.float32) for _ in range(case["channels"])]
+        mix_buffers(target, [mono] if case["fn"] == "mono" else [left, right])
+        assert case["n_after"] == n
+        out.append((case, target))
+    return out
+
+
+def test_g9_render_buffer_conventions(oracle):
+    g = load_golden("g9_render_conventions.json")
+    assert g["errors"]["nan"][0] == "TypeError" and g["errors"]["three_channels"][0] == "RangeError"
+    for case, target in render_conventions_via_mix(oracle.mix_buffers, g):
+        for ch, exp in enumerate(case["out"]):
+            assert_bits_equal(target[ch], exp, "%s fn into %d channel(s), ch%d" % (case["fn"], case["channels"], ch))
+
+
+def test_g10_loop_node_bpm_getter(oracle):
+    g = load_golden("g10_loop_bpm.json")
+    for r in g["rows"]:
+        br0 = oracle.beat_rate(r["sr"], r["bpm"])
+        back = oracle.bpm_from_beat_rate(r["sr"], br0)
+        assert back == r["bpm_back"], r
+        assert oracle.beat_rate(r["sr"], back) == r["beat_rate"] and 4 * r["beat_rate"] == r["buffer_size"]
+    for t in g["ties"]:
+        assert oracle.bpm_from_beat_rate(t["sr"], t["beat_rate"]) == t["bpm_back"], t
+    for b in load_golden("g6_ring_and_loop.json")["beat"]:
+        assert oracle.bpm_from_beat_rate(b["sr"], b["beat_rate"]) == b["bpm_back"]
+
+
+def test_javascript_restatement_is_pinned_to_the_same_fixtures():
+    """oracle/oracle_go.mjs (the Node.js CPU baseline bench.py times) reproduces the reference-generated
+    fixtures g1, g4, g8 and the C1-sized run bit for bit."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    node = shutil.which("node")
+    if not node:
+        pytest.skip("node is not installed")
+    out = subprocess.run([node, "--no-warnings", os.path.join(ROOT, "oracle", "oracle_go.mjs"), "check"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr

@@ -1,9 +1,13 @@
-"""The N>1 path on CPU: two gloo ranks shard the tracks, each builds its partial
-master bus, and ONE reduce combines them (dsp_amd.device.shard_range /
-reduce_master_bus — the same code the GPU ranks run over RCCL).  The per-rank
-buses come from the oracle here (no GPU in this test); the check is that the
-sharded + reduced bus equals the single-process mix to <= 1e-5 of full scale
-(the accumulation order differs, so bit-exactness is not expected)."""
+"""The N>1 path rehearsed with two gloo ranks: the tracks are sharded
+(dsp_amd.device.shard_range), each rank builds its partial master bus, and ONE
+reduce combines them (reduce_master_bus).  Without a GPU the per-rank buses come
+from the oracle; the `gpu` variant runs the same flow with both ranks on the one
+MI355X of the test box, each rank computing its bus with the HIP path
+(BatchedConvolver.run_and_mix) and the reduce staged through gloo, because RCCL
+refuses two ranks on one device (the RCCL reduce itself: test_gpu_device_api.py,
+one rank).  Either way the sharded + reduced bus must equal the single-process
+oracle mix to <= 1e-5 of full scale (the accumulation order differs, so
+bit-exactness is not expected)."""
 import os
 import socket
 import sys
@@ -22,27 +26,42 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tracks, L, M, q):
+def _worker(rank, world, port, tracks, L, M, q, use_gpu=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
     from dsp_amd import device
-    from oracle import oracle as o
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = device.shard_range(tracks, rank, world)
-    irs = [o.synth_ir(M, 500000), o.synth_ir(M, 500001)]
-    bus = [np.zeros(L, np.float32), np.zeros(L, np.float32)]
-    srcs = []
-    for t in range(lo, hi):
-        y = [o.fft_convolution(L, o.fft_process_kernel(L, irs[ch]), M)(o.synth_noise(L, 1000 + 2 * t + ch)) for ch in range(2)]
-        srcs.append(([y[0][:L], y[1][:L]], 1, 1.0 / tracks, 0))
-    o.mix_buffers(bus, *srcs)
-    tb = torch.from_numpy(np.stack(bus))
+    if use_gpu:
+        # the product path: device-resident noise, batched go() per channel-job and the mix in one pass
+        torch.cuda.set_device(0)
+        irs = torch.from_numpy(np.stack([device.synth_ir(M, 500000), device.synth_ir(M, 500001)])).cuda()
+        ir = device.DeviceIR(irs, L)
+        n = hi - lo
+        conv = device.BatchedConvolver(ir, [j % 2 for j in range(2 * n)])
+        x = torch.empty((2 * n, L), dtype=torch.float32, device="cuda")
+        for j in range(2 * n):
+            device.synth_noise(x[j], 1000 + 2 * (lo + j // 2) + (j % 2))
+        out = torch.empty((2 * n, L + M), dtype=torch.float32, device="cuda")
+        tb = torch.zeros((2, L), dtype=torch.float32, device="cuda")
+        conv.run_and_mix(x, out, [tb[0], tb[1]], [1.0 / tracks] * n)
+        torch.cuda.synchronize()
+    else:
+        from oracle import oracle as o
+        irs = [o.synth_ir(M, 500000), o.synth_ir(M, 500001)]
+        bus = [np.zeros(L, np.float32), np.zeros(L, np.float32)]
+        srcs = []
+        for t in range(lo, hi):
+            y = [o.fft_convolution(L, o.fft_process_kernel(L, irs[ch]), M)(o.synth_noise(L, 1000 + 2 * t + ch)) for ch in range(2)]
+            srcs.append(([y[0][:L], y[1][:L]], 1, 1.0 / tracks, 0))
+        o.mix_buffers(bus, *srcs)
+        tb = torch.from_numpy(np.stack(bus))
     device.reduce_master_bus(tb, dist, dst=0)
     if rank == 0:
-        q.put(tb.numpy().copy())
+        q.put(tb.cpu().numpy().copy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,12 +77,21 @@ def test_shard_range_is_a_partition():
 
 
 def test_two_rank_sharded_mix_matches_single_process(oracle):
+    _two_ranks(oracle, False)
+
+
+@pytest.mark.gpu
+def test_two_rank_sharded_mix_hip_path(oracle):
+    _two_ranks(oracle, True)
+
+
+def _two_ranks(oracle, use_gpu):
     import torch.multiprocessing as mp
     tracks, L, M, world = 5, 3000, 700, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, tracks, L, M, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tracks, L, M, q, use_gpu)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)
