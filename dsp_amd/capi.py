@@ -43,6 +43,9 @@ PROTOTYPES = {
     "wp_ir_info": (C.c_int64, [C.c_void_p, C.c_int]),
     "wp_convolve": (C.c_int, [C.c_void_p, C.c_int, f32p, C.c_int64, f32p]),
     "wp_convolve_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "wp_direct_convolution": (C.c_int, [f32p, C.c_int64, f32p, C.c_int64, f32p]),
+    "wp_kernel_spectrum": (C.c_int, [f32p, C.c_int64, C.c_int64, f32p]),
+    "wp_kernel_from_spectrum": (C.c_int, [f32p, C.c_int64, C.c_int64, f32p]),
     "wp_convolve_dev_noalloc": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "wp_conv_create": (C.c_void_p, [C.c_void_p, C.c_int, i32p]),
     "wp_conv_destroy": (None, [C.c_void_p]),

@@ -8,7 +8,10 @@
 2N-float interleaved spectrum; here the spectra live on the GPU as partitioned
 half-spectra, so the object carries the raw IR samples (what a cache needs in
 order to rebuild the device state elsewhere) and reports the length the
-reference's array would have.
+reference's array would have.  With ``compat=True`` it returns the reference's own
+array instead (2N float32, the interleaved N-point spectrum), and
+`fft_convolution` accepts such an array -- from here or from the reference --
+by transforming it back to the impulse response on the GPU.
 """
 import ctypes as C
 
@@ -84,16 +87,36 @@ class KernelSpectrum:
         return self._ir
 
 
-def fft_process_kernel(length, kernel):
+def fft_process_kernel(length, kernel, compat=False):
     k = KernelSpectrum(length, kernel)
+    if compat:  # the reference's layout: interleaved spectrum of the kernel zero-padded to N points
+        h = _c32(kernel)
+        out = np.empty(k.length, dtype=np.float32)
+        capi.check(capi.lib().wp_kernel_spectrum(_fp(h), len(h), int(length), _fp(out)), "fftProcessKernel")
+        return out
     k.ir()  # build the device spectra now, like the reference does its FFT here
     return k
 
 
+def _kernel_from_reference_spectrum(length, spectrum, kernel_length):
+    """A Float32Array(2N) in the reference's layout (lib/convolve.js:575-579 multiplies by whatever
+    array of that length it is given) -> KernelSpectrum, through one inverse transform on the GPU."""
+    spec = _c32(spectrum)
+    n = capi.check(capi.lib().wp_fft_length(int(length), int(kernel_length)), "fftConvolution")
+    if len(spec) != 2 * n:
+        raise ValueError("a reference-layout kernel for length=%d, kernel_length=%d has %d floats, not %d"
+                         % (length, kernel_length, 2 * n, len(spec)))
+    h = np.empty(int(kernel_length), dtype=np.float32)
+    capi.check(capi.lib().wp_kernel_from_spectrum(_fp(spec), n, int(kernel_length), _fp(h)), "fftConvolution")
+    return KernelSpectrum(length, h)
+
+
 def fft_convolution(length, fft_kernel, kernel_length):
     """-> go(input): Float32 array of exactly length + kernel_length samples."""
+    if isinstance(fft_kernel, np.ndarray):
+        fft_kernel = _kernel_from_reference_spectrum(length, fft_kernel, kernel_length)
     if not isinstance(fft_kernel, KernelSpectrum):
-        raise TypeError("fft_kernel must come from fft_process_kernel")
+        raise TypeError("fft_kernel must come from fft_process_kernel or be a reference-layout spectrum")
     if fft_kernel.block_length != int(length) or len(fft_kernel.ir_samples) != int(kernel_length):
         raise ValueError("fft_kernel was prepared for length=%d kernel_length=%d" %
                          (fft_kernel.block_length, len(fft_kernel.ir_samples)))
@@ -111,8 +134,9 @@ def fft_convolution(length, fft_kernel, kernel_length):
 
 
 def direct_convolution(x, h):
-    """lib/convolve.js:541-551.  O(L*M); served by the same GPU path (a direct
-    sum and the FFT route agree to rounding), returning L+M-1 samples."""
+    """lib/convolve.js:541-551: n+m-1 samples, bit-identical to the reference (the GPU
+    kernel keeps the reference's accumulation chain per output sample)."""
     x, h = _c32(x), _c32(h)
-    k = fft_process_kernel(len(x), h)
-    return fft_convolution(len(x), k, len(h))(x)[:len(x) + len(h) - 1]
+    out = np.zeros(max(len(x) + len(h) - 1, 0), dtype=np.float32)
+    capi.check(capi.lib().wp_direct_convolution(_fp(x), len(x), _fp(h), len(h), _fp(out)), "directConvolution")
+    return out

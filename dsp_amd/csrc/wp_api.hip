@@ -947,6 +947,76 @@ extern "C" int wp_convolve(wp_ir *ir, int ch, const float *in, int64_t in_len, f
 }
 
 // ---------------------------------------------------------------------------
+// lib/convolve.js:541-551 and the reference-layout kernel object (:553-562)
+struct DevTmp {  // device allocations of one host-pointer call, freed on every return path
+    std::vector<void *> p;
+    ~DevTmp()
+    {
+        for (void *q : p) (void)hipFree(q);
+    }
+    hipError_t get(void **out, size_t bytes)
+    {
+        const hipError_t e = hipMalloc(out, bytes ? bytes : 4);
+        if (e == hipSuccess) p.push_back(*out);
+        return e;
+    }
+};
+
+extern "C" int wp_direct_convolution(const float *input, int64_t n, const float *kernel, int64_t m, float *out)
+{
+    if (int rc = need_device()) return rc;
+    if (n < 0 || m < 0 || (n > 0 && !input) || (m > 0 && !kernel)) return fail(WP_ERR_INVALID, "wp_direct_convolution: bad argument");
+    const int64_t len = n + m - 1;
+    if (len <= 0) return WP_OK;
+    if (!out) return fail(WP_ERR_INVALID, "wp_direct_convolution: null output");
+    DevTmp tmp;
+    float *dx = nullptr, *dh = nullptr, *dy = nullptr;
+    HIPCHK(tmp.get((void **)&dx, sizeof(float) * (size_t)n));
+    HIPCHK(tmp.get((void **)&dh, sizeof(float) * (size_t)m));
+    HIPCHK(tmp.get((void **)&dy, sizeof(float) * (size_t)len));
+    if (n > 0) HIPCHK(hipMemcpy(dx, input, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+    if (m > 0) HIPCHK(hipMemcpy(dh, kernel, sizeof(float) * (size_t)m, hipMemcpyHostToDevice));
+    HIPCHK(launch_direct_conv(dx, n, dh, m, dy, nullptr));
+    HIPCHK(hipMemcpy(out, dy, sizeof(float) * (size_t)len, hipMemcpyDeviceToHost));
+    return WP_OK;
+}
+
+static int big_fft_host(const float *src, int64_t n_src, int64_t n_real, int64_t N, int inverse, float *dst, int64_t n_out,
+                        const char *who)
+{
+    if (N < 2 || (N & (N - 1)) != 0) return fail(WP_ERR_FFT_SIZE, "FFT size must be a power of two and bigger than 1");
+    if (N > ((int64_t)1 << 27)) return fail(WP_ERR_UNSUPPORTED, "%s: spectra of more than 2^27 points are not implemented", who);
+    DevTmp tmp;
+    float *dsrc = nullptr, *ddst = nullptr;
+    void *w0 = nullptr, *w1 = nullptr;
+    HIPCHK(tmp.get((void **)&dsrc, sizeof(float) * (size_t)n_src));
+    HIPCHK(tmp.get((void **)&ddst, sizeof(float) * (size_t)n_out));
+    HIPCHK(tmp.get(&w0, 16 * (size_t)N));
+    HIPCHK(tmp.get(&w1, 16 * (size_t)N));
+    if (n_src > 0) HIPCHK(hipMemcpy(dsrc, src, sizeof(float) * (size_t)n_src, hipMemcpyHostToDevice));
+    HIPCHK(launch_big_fft(dsrc, n_real, N, inverse, w0, w1, ddst, inverse ? n_out : N, nullptr));
+    HIPCHK(hipMemcpy(dst, ddst, sizeof(float) * (size_t)n_out, hipMemcpyDeviceToHost));
+    return WP_OK;
+}
+
+extern "C" int wp_kernel_spectrum(const float *kernel, int64_t M, int64_t L, float *spectrum_out)
+{
+    if (int rc = need_device()) return rc;
+    if (!kernel || !spectrum_out) return fail(WP_ERR_INVALID, "wp_kernel_spectrum: null argument");
+    if (int rc = check_ir_args(1, M, L)) return rc;
+    const int64_t N = wp_next_pot((int32_t)(L + M));
+    return big_fft_host(kernel, M, M, N, 0, spectrum_out, 2 * N, "wp_kernel_spectrum");
+}
+
+extern "C" int wp_kernel_from_spectrum(const float *spectrum, int64_t N, int64_t M, float *kernel_out)
+{
+    if (int rc = need_device()) return rc;
+    if (!spectrum || !kernel_out) return fail(WP_ERR_INVALID, "wp_kernel_from_spectrum: null argument");
+    if (M < 1 || M > N) return fail(WP_ERR_INVALID, "wp_kernel_from_spectrum: kernel length %lld does not fit %lld points", (long long)M, (long long)N);
+    return big_fft_host(spectrum, 2 * N, 0, N, 1, kernel_out, M, "wp_kernel_from_spectrum");
+}
+
+// ---------------------------------------------------------------------------
 extern "C" wp_reverb *wp_reverb_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t offset)
 {
     if (need_device()) return nullptr;
@@ -1186,7 +1256,14 @@ extern "C" int wp_mix(float *const *tgt, int tch, int64_t tl, const wp_src *srcs
             total += al(bytes);
         }
     };
-    for (int c = 0; c < tch; c++) place(tgt[c], sizeof(float) * (size_t)tl);
+    // the target gets a staging copy of its own: a source that is the very same host array
+    // (mixBuffers(t, t)) is then read as it was before the call instead of overlapping the
+    // range the kernel updates in place
+    size_t tgt_off[2] = {0, 0};
+    for (int c = 0; c < tch; c++) {
+        tgt_off[c] = total;
+        total += al(sizeof(float) * (size_t)tl);
+    }
     for (int64_t i = 0; i < nsrc; i++) {
         const wp_src &S = srcs[i];
         if (S.nch != 1 && S.nch != 2) continue;
@@ -1217,6 +1294,10 @@ extern "C" int wp_mix(float *const *tgt, int tch, int64_t tl, const wp_src *srcs
     }
     char *d = stage.p;
     int rc = WP_OK;
+    for (int c = 0; c < tch; c++) {
+        hipError_t e = hipMemcpy(d + tgt_off[c], tgt[c], sizeof(float) * (size_t)tl, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(WP_ERR_HIP, "hipMemcpy(H2D) failed: %s", hipGetErrorString(e));
+    }
     for (auto &kv : where) {
         if (kv.first.second == 0) continue;
         hipError_t e = hipMemcpy(d + kv.second, kv.first.first, kv.first.second, hipMemcpyHostToDevice);
@@ -1235,7 +1316,7 @@ extern "C" int wp_mix(float *const *tgt, int tch, int64_t tl, const wp_src *srcs
     }
     float *td[2] = {nullptr, nullptr};
     for (int c = 0; c < tch; c++)
-        td[c] = reinterpret_cast<float *>(d + where[std::make_pair((const void *)tgt[c], sizeof(float) * (size_t)tl)]);
+        td[c] = reinterpret_cast<float *>(d + tgt_off[c]);
     rc = wp_mix_dev(td, tch, tl, ds.data(), nsrc, 0, nullptr);
     if (rc == WP_OK) {
         for (int c = 0; c < tch && rc == WP_OK; c++) {

@@ -41,6 +41,11 @@ hipError_t launch_fft_inv_mix(int B, const c32 *W, int T, int nblocks, int nsrc,
                               const double *vol, float *out, int64_t out_stride, int64_t out_len, const c32 *tables,
                               hipStream_t s);
 
+hipError_t launch_direct_conv(const float *x, int64_t n, const float *h, int64_t m, float *out, hipStream_t s);
+// N-point complex transform in binary64 over global memory (work0/work1: 16*N bytes each)
+hipError_t launch_big_fft(const float *src, int64_t n_real, int64_t N, int inverse, void *work0, void *work1, float *dst,
+                          int64_t n_out, hipStream_t s);
+
 size_t mix_scratch_bytes(int64_t nsrc);  // bytes of device scratch launch_mix needs
 hipError_t launch_mix(float *t0, float *t1, int tch, int64_t tl, const wp_src *srcs_dev, void *scratch,
                       int64_t nsrc, hipStream_t s);

@@ -760,6 +760,63 @@ static napi_value js_bpm_from_beat_rate(napi_env env, napi_callback_info info)
     return num(env, wp_bpm_from_beat_rate(sr, br));
 }
 
+// directConvolution(input, kernel) -> Float32Array(n+m-1), bit-identical to lib/convolve.js:541-551
+static napi_value js_direct_convolution(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    F32View x, h;
+    if (!get_f32(env, argv[0], &x) || !get_f32(env, argv[1], &h)) {
+        napi_throw_type_error(env, NULL, "directConvolution(Float32Array, Float32Array)");
+        return NULL;
+    }
+    const size_t len = x.length + h.length > 0 ? x.length + h.length - 1 : 0;
+    float *out = NULL;
+    napi_value ta = new_f32(env, len, &out);
+    if (!ta) return NULL;
+    const int rc = wp_direct_convolution(x.data, (int64_t)x.length, h.data, (int64_t)h.length, out);
+    if (rc) return throw_wp(env, rc);
+    return ta;
+}
+
+// kernelSpectrum(kernel, L, out): the reference-layout spectrum (2N floats) into `out`
+static napi_value js_kernel_spectrum(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    F32View h, out;
+    int64_t L;
+    if (!get_f32(env, argv[0], &h) || !get_i64(env, argv[1], &L) || !get_f32(env, argv[2], &out)) {
+        napi_throw_type_error(env, NULL, "kernelSpectrum(Float32Array, length, Float32Array)");
+        return NULL;
+    }
+    const int32_t N = wp_fft_length(L, (int64_t)h.length);
+    if (N < 0) return throw_wp(env, N);
+    if (out.length < 2 * (size_t)N) {
+        napi_throw_range_error(env, NULL, "kernelSpectrum: the output holds fewer than 2N floats");
+        return NULL;
+    }
+    const int rc = wp_kernel_spectrum(h.data, (int64_t)h.length, L, out.data);
+    if (rc) return throw_wp(env, rc);
+    return argv[2];
+}
+
+// kernelFromSpectrum(spectrum /* 2N */, M) -> Float32Array(M)
+static napi_value js_kernel_from_spectrum(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    F32View spec;
+    int64_t M;
+    if (!get_f32(env, argv[0], &spec) || !get_i64(env, argv[1], &M) || M < 1 || spec.length % 2) {
+        napi_throw_type_error(env, NULL, "kernelFromSpectrum(Float32Array(2N), M)");
+        return NULL;
+    }
+    float *out = NULL;
+    napi_value ta = new_f32(env, (size_t)M, &out);
+    if (!ta) return NULL;
+    const int rc = wp_kernel_from_spectrum(spec.data, (int64_t)(spec.length / 2), M, out);
+    if (rc) return throw_wp(env, rc);
+    return ta;
+}
+
 // ---- multi-GPU: one process per GPU, the partial master buses summed by RCCL ------
 static void comm_finalize(napi_env, void *p, void *) { wp_comm_destroy((wp_comm *)p); }
 
@@ -846,6 +903,9 @@ NAPI_MODULE_INIT()
         {"ringPos", NULL, js_ring_pos, NULL, NULL, NULL, napi_enumerable, NULL},
         {"beatRate", NULL, js_beat_rate, NULL, NULL, NULL, napi_enumerable, NULL},
         {"bpmFromBeatRate", NULL, js_bpm_from_beat_rate, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"directConvolution", NULL, js_direct_convolution, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"kernelSpectrum", NULL, js_kernel_spectrum, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"kernelFromSpectrum", NULL, js_kernel_from_spectrum, NULL, NULL, NULL, napi_enumerable, NULL},
         {"commUniqueId", NULL, js_comm_unique_id, NULL, NULL, NULL, napi_enumerable, NULL},
         {"commCreate", NULL, js_comm_create, NULL, NULL, NULL, napi_enumerable, NULL},
         {"busReduce", NULL, js_bus_reduce, NULL, NULL, NULL, napi_enumerable, NULL},

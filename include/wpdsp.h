@@ -87,6 +87,22 @@ int wp_convolve(wp_ir *ir, int ch, const float *in, int64_t in_len, float *out);
 /* The same with input and result in device memory (in_len floats in, L+M out). */
 int wp_convolve_dev(wp_ir *ir, int ch, const float *in_dev, int64_t in_len, float *out_dev, void *stream);
 
+/* lib/convolve.js:541-551 directConvolution(input, kernel): out receives n+m-1
+ * floats, each the reference's own chain (per output sample, input index
+ * ascending: binary64 multiply, binary64 add, binary32 store), so the result is
+ * bit-identical to the reference's.  Host pointers. */
+int wp_direct_convolution(const float *input, int64_t n, const float *kernel, int64_t m, float *out);
+/* The kernel object in the reference's own layout (lib/convolve.js:553-562,588-595):
+ * the interleaved complex spectrum of the kernel zero-padded to N = wp_fft_length(L, M)
+ * points, 2N floats.  Computed with binary64 butterflies and rounded once, so it
+ * equals the reference's array to the reference's own rounding noise (the
+ * reference rounds to binary32 after every radix-4 pass).  Host pointers. */
+int wp_kernel_spectrum(const float *kernel, int64_t M, int64_t L, float *spectrum_out /* 2N */);
+/* The way back: the first M samples of the inverse transform's real part.  Lets
+ * fftConvolution accept a spectrum that the reference's fftProcessKernel produced
+ * (lib/convolve.js:575-579 uses any Float32Array(2N) as the kernel). */
+int wp_kernel_from_spectrum(const float *spectrum /* 2N */, int64_t N, int64_t M, float *kernel_out /* M */);
+
 /* No counterpart in the reference.  wp_convolve_dev for callers that cannot
  * allocate device memory when they call (code under HIP stream capture, tight
  * serving loops, harnesses that forbid hipMalloc): the block spectra live in a

@@ -45,12 +45,22 @@ const main = async () => {
     const x = f32(c.x), h = f32(c.h)
     const k = convolve.fftProcessKernel(c.L, h)
     if (!(k instanceof Float32Array)) fail('kernel type')
-    if (c.kernel_len >= h.length + 4 && k.length !== c.kernel_len) fail('kernel length ' + k.length + ' != ' + c.kernel_len)
+    if (k.length !== c.kernel_len) fail('kernel length ' + k.length + ' != ' + c.kernel_len)
     if (!(k.buffer instanceof SharedArrayBuffer)) fail('kernel not shared')
     const y = convolve.fftConvolution(c.L, k, h.length)(x)
     if (y.byteOffset !== c.out_byte_offset || y.buffer.byteLength !== c.out_buffer_bytes) fail('result view shape')
     close(y, f32(c.out), 'go L=' + c.L)
-    close(convolve.directConvolution(x, h), f32(c.direct), 'direct L=' + c.L)
+    same(convolve.directConvolution(x, h), c.direct, 'direct L=' + c.L)
+    // the kernel object the reference itself produced (its interleaved spectrum) is accepted as it is
+    const refKernel = f32(c.kernel)
+    close(convolve.fftConvolution(c.L, refKernel, h.length)(x), f32(c.out), 'go with the reference\'s own kernel, L=' + c.L)
+    // and the compat switch returns that layout: equal to the reference's array to its rounding noise
+    const ck = convolve.fftProcessKernel(c.L, h, true, true)
+    if (ck.length !== c.kernel_len || !(ck.buffer instanceof SharedArrayBuffer)) fail('compat kernel shape')
+    let peak = 0
+    for (let i = 0; i < refKernel.length; i++) peak = Math.max(peak, Math.abs(refKernel[i]))
+    for (let i = 0; i < refKernel.length; i++) if (Math.abs(ck[i] - refKernel[i]) > 2e-6 * Math.max(1, peak)) fail('compat spectrum differs at ' + i)
+    checks++
   }
   // error classes
   try { convolve.fftConvolution(4, convolve.fftProcessKernel(4, new Float32Array(4)), 4)(new Float32Array(9)); fail('no RangeError') } catch (e) { if (!(e instanceof RangeError)) throw e; checks++ }

@@ -49,7 +49,31 @@ def test_g1_tiny_go_vectors(wp):
         assert len(y) == c["out_len"] and y.dtype == np.float32
         _close(y, from_bits(c["out"]), "go L=%d M=%d" % (c["L"], c["M"]))
         d = wp.convolve.direct_convolution(x, h)
-        _close(d, from_bits(c["direct"]), "direct L=%d" % c["L"])
+        assert_bits_equal(d, c["direct"], "direct L=%d" % c["L"])  # the reference's own accumulation chain per sample
+        # the kernel object the reference itself produced (its interleaved spectrum) is accepted as it is
+        ref_kernel = from_bits(c["kernel"])
+        y2 = wp.convolve.fft_convolution(c["L"], ref_kernel, len(h))(x)
+        _close(y2, from_bits(c["out"]), "go with the reference's own kernel, L=%d" % c["L"])
+        # and compat=True returns that layout, equal to the reference's array to its rounding noise
+        ck = wp.convolve.fft_process_kernel(c["L"], h, compat=True)
+        assert ck.dtype == np.float32 and len(ck) == c["kernel_len"]
+        assert float(np.abs(ck.astype(np.float64) - ref_kernel).max()) <= 2e-6 * max(1.0, float(np.abs(ref_kernel).max()))
+
+
+def test_reference_layout_kernels_at_config_size(wp, oracle):
+    """The reference-layout kernel at the C1 size (N = 131 072): the spectrum the oracle computes the
+    reference's way is accepted by fft_convolution, compat=True reproduces it to rounding noise, and
+    direct_convolution matches the oracle's bit for bit on a case with thousands of terms per sample."""
+    L, M = 44100, 22050
+    h, x = oracle.synth_ir(M, 500000), oracle.synth_noise(L, 1000)
+    ref_kernel = oracle.fft_process_kernel(L, h)
+    want = oracle.fft_convolution(L, ref_kernel, M)(x)
+    _close(wp.convolve.fft_convolution(L, ref_kernel, M)(x), want, "go with an oracle-made reference-layout kernel")
+    ck = wp.convolve.fft_process_kernel(L, h, compat=True)
+    assert len(ck) == len(ref_kernel) == 2 * 131072
+    assert float(np.abs(ck.astype(np.float64) - ref_kernel).max()) <= 2e-6 * float(np.abs(ref_kernel).max())
+    xs, hs = oracle.synth_noise(5000, 3), oracle.synth_ir(3000, 4)
+    assert_bits_equal(wp.convolve.direct_convolution(xs, hs), oracle.direct_convolution(xs, hs).view(np.uint32), "direct 5000 x 3000")
 
 
 def test_error_behaviour(wp):
@@ -126,6 +150,20 @@ def test_g4_mix_buffers_bit_exact(wp):
         assert ret is target
         for ch, exp in enumerate(case["target_out"]):
             assert_bits_equal(target[ch], exp, case["name"] + " ch%d" % ch)
+
+
+def test_mix_source_is_the_target_itself(wp, oracle):
+    """mixBuffers(t, t): every index is read before it is written in the reference (same length, no
+    offset), so the target doubles; the host-array entry point stages the target apart from its sources."""
+    t = [oracle.synth_noise(1000, 77), oracle.synth_noise(1000, 78)]
+    want = [(a.astype(np.float64) + a.astype(np.float64) * 1.0).astype(np.float32) for a in t]
+    wp.mix.mix_buffers(t, t)
+    for ch in range(2):
+        assert np.array_equal(t[ch], want[ch])
+    m = [oracle.synth_noise(64, 79)]
+    want = [(m[0].astype(np.float64) + m[0].astype(np.float64) * 0.5).astype(np.float32)]
+    wp.mix.mix_buffers(m, (m, 1, 0.5, 0))
+    assert np.array_equal(m[0], want[0])
 
 
 def test_mix_vs_oracle_random_shapes(wp, oracle):
