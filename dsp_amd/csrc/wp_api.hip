@@ -368,6 +368,10 @@ extern "C" int wp_tune(int what, int64_t value)
         if (value < 0 || value > 2) break;
         g_tune_mac = (int)value;
         return WP_OK;
+    case WP_TUNE_FWD_FORM:
+        if (value < 0 || value > 2) break;
+        set_fwd_pair(value != 1);
+        return WP_OK;
     case WP_TUNE_POOL_MB:
         if (value < 0 || value > (1 << 20)) break;
         g_tune_pool_mb = (long)value;

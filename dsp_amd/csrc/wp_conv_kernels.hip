@@ -18,17 +18,26 @@ namespace wp {
 // streaming accesses: every spectrum row is written once and read once by a later
 // kernel, tens of gigabytes apart, so it is marked non-temporal
 typedef float v2f __attribute__((ext_vector_type(2)));
+// (WP_PLAIN_SPECTRA builds them as plain accesses: an experiment switch for cache-resident chunked runs)
 __device__ __forceinline__ c32 ld_nt(const c32 *p)
 {
+#ifdef WP_PLAIN_SPECTRA
+    return *p;
+#else
     const v2f t = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
     return c32{t.x, t.y};
+#endif
 }
 __device__ __forceinline__ void st_nt(c32 *p, c32 v)
 {
+#ifdef WP_PLAIN_SPECTRA
+    *p = v;
+#else
     v2f t;
     t.x = v.x;
     t.y = v.y;
     __builtin_nontemporal_store(t, reinterpret_cast<v2f *>(p));
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -112,6 +121,79 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_fwd(const float *__r
     middle_stages<B, false>(tid, v, lds, tw);
     c32 *z = Z + ((int64_t)job * T + t) * B;
     stage_store<B, FftPlan<B>::NSTAGE - 1, false>(tid, v, [&](int i, c32 val, int, int) { st_nt(z + i, val); });
+}
+
+// ---------------------------------------------------------------------------
+// Forward, two segments per workgroup: segments t0 = 2*blockIdx.x and t0+1 share the B samples
+// x[t0*B, (t0+1)*B).  With 16 points per thread and a radix-16 first stage a thread's first eight
+// inputs come from the segment's first half and its last eight from the second half, so the
+// shared half of segment t0+1 is exactly the thread's own last eight raw inputs of segment t0:
+// they stay in registers, and every input sample of a pair is fetched once (three half-segments
+// per two transforms instead of four).
+template <int B>
+__global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_fwd_pair(const float *__restrict__ in, int64_t in_stride,
+                                                                    int64_t in_len, c32 *__restrict__ Z, int T, int nblocks,
+                                                                    const c32 *__restrict__ tables)
+{
+    constexpr int PT = FftPlan<B>::PT, NT = B / PT, H = PT / 2;
+    static_assert(PT == 16 && FftPlan<B>::radix(0) == 16, "a thread's inputs must split into halves of the segment");
+    extern __shared__ __align__(16) unsigned char smem[];
+    c32 *lds = reinterpret_cast<c32 *>(smem);
+    c32 *tws = lds + lds_points<B>();
+    const int tid = threadIdx.x;
+    const int t0 = 2 * blockIdx.x;
+    const int job = blockIdx.y;
+    const bool two = t0 + 1 < nblocks;
+    const TwTables<B> tw = load_tables<B, false>(tables, tws, tid);
+    const float *x = in + (int64_t)job * in_stride;
+    const int64_t seg = ((int64_t)t0 - 1) * B;  // first sample of segment t0; the pair spans [seg, seg + 3B)
+    // complex point n of half-segment q (q = 0, 1, 2): samples seg + q*B + 2n, +1
+    c32 v[PT], keep[H];
+    const int64_t span = two ? 3 * (int64_t)B : 2 * (int64_t)B;
+    const bool fast = seg >= 0 && seg + span <= in_len && ((reinterpret_cast<uintptr_t>(x + seg) & 7) == 0);
+    auto sample2 = [&](int64_t g) {  // samples g, g+1 with zeros outside [0, in_len)
+        c32 r;
+        r.x = (g >= 0 && g < in_len) ? x[g] : 0.0f;
+        r.y = (g + 1 >= 0 && g + 1 < in_len) ? x[g + 1] : 0.0f;
+        return r;
+    };
+    if (fast) {
+        const c32 *xs = reinterpret_cast<const c32 *>(x + seg);
+        static_for<0, PT>([&](auto t) { v[t] = xs[tid + int(t) * NT]; });
+    } else {
+        static_for<0, PT>([&](auto t) { v[t] = sample2(seg + 2 * (int64_t)(tid + int(t) * NT)); });
+    }
+    static_for<0, H>([&](auto t) { keep[t] = v[H + t]; });
+    // the third half-segment is requested now, so that it arrives behind the first transform
+    // (fetched only after it, the kernel measured 8 % slower than one segment per workgroup;
+    // this way 2.6 % faster)
+    c32 next[H];
+    if (two) {
+        if (fast) {
+            const c32 *xs = reinterpret_cast<const c32 *>(x + seg);
+            static_for<0, H>([&](auto t) { next[t] = xs[B + tid + int(t) * NT]; });
+        } else {
+            static_for<0, H>([&](auto t) { next[t] = sample2(seg + 2 * (int64_t)(B + tid + int(t) * NT)); });
+        }
+    }
+    const c32 *thalf = tables + table_thalf_offset(B);
+    pre_twist<B>(tid, v, thalf);
+    middle_stages<B, false>(tid, v, lds, tw);
+    c32 *z = Z + ((int64_t)job * T + t0) * B;
+    stage_store<B, FftPlan<B>::NSTAGE - 1, false>(tid, v, [&](int i, c32 val, int, int) { st_nt(z + i, val); });
+    if (!two) return;
+    static_for<0, H>([&](auto t) { v[H + t] = next[t]; });
+    static_for<0, H>([&](auto t) { v[t] = keep[t]; });
+    __syncthreads();  // every lane has taken its last-stage inputs out of LDS
+    // The twiddles depend on the thread index only.  Left to itself the compiler keeps the first
+    // transform's twiddle powers (15 complex values per stage) alive for the second one, which
+    // costs some 50 registers; hiding the index behind an empty asm makes it recompute them.
+    int tid2 = tid;
+    asm volatile("" : "+v"(tid2));
+    pre_twist<B>(tid2, v, thalf);
+    middle_stages<B, false>(tid2, v, lds, tw);
+    z += B;
+    stage_store<B, FftPlan<B>::NSTAGE - 1, false>(tid2, v, [&](int i, c32 val, int, int) { st_nt(z + i, val); });
 }
 
 // ---------------------------------------------------------------------------
@@ -254,7 +336,11 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv_mix(const c32 *_
     };
 
     // two register sets: the next source's spectrum is in flight while this one is transformed
-    // (capping the 512-thread plan at 128 VGPRs for a second workgroup per CU measured 2x slower)
+    // (capping the 512-thread plan at 128 VGPRs for a second workgroup per CU measured 2x slower).
+    // The twiddle powers depend on the thread index only, so the compiler hoists them out of the
+    // source loop and keeps them in some 90 registers (234 in all, two workgroups per CU);
+    // recomputing them per source instead (144 registers, three workgroups per CU) measured 3 %
+    // slower: the kernel is not bound by occupancy.
     if constexpr (PT <= 16) {
         c32 v[PT], vn[PT];
         fetch(0, vn);
@@ -500,6 +586,9 @@ static hipError_t set_lds_attr(const void *fn)
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds_bytes<B>());
 }
 
+static bool g_fwd_pair = true;  // forward transform: two segments per workgroup (false: one)
+void set_fwd_pair(bool on) { g_fwd_pair = on; }
+
 template <int B>
 static hipError_t launch_fwd_t(bool irmode, const float *in, int64_t in_stride, int64_t in_len, c32 *Z, int T,
                                int nblocks, int njobs, const c32 *tables, hipStream_t s)
@@ -507,11 +596,15 @@ static hipError_t launch_fwd_t(bool irmode, const float *in, int64_t in_stride, 
     if ((fft_lds_bytes<B, false>()) > 48 * 1024) {  // opt in to more than the default dynamic LDS
         hipError_t e = irmode ? set_lds_attr<B>((const void *)k_fft_fwd<B, true>)
                               : set_lds_attr<B>((const void *)k_fft_fwd<B, false>);
+        if (e == hipSuccess && !irmode) e = set_lds_attr<B>((const void *)k_fft_fwd_pair<B>);
         if (e != hipSuccess) return e;
     }
     const dim3 grid(nblocks, njobs), block(B / FftPlan<B>::PT);
     if (irmode)
         hipLaunchKernelGGL((k_fft_fwd<B, true>), grid, block, (fft_lds_bytes<B, false>()), s, in, in_stride, in_len, Z, T, tables);
+    else if (g_fwd_pair && nblocks > 1)
+        hipLaunchKernelGGL((k_fft_fwd_pair<B>), dim3((nblocks + 1) / 2, njobs), block, (fft_lds_bytes<B, false>()), s, in,
+                           in_stride, in_len, Z, T, nblocks, tables);
     else
         hipLaunchKernelGGL((k_fft_fwd<B, false>), grid, block, (fft_lds_bytes<B, false>()), s, in, in_stride, in_len, Z, T, tables);
     return hipGetLastError();

@@ -27,6 +27,7 @@ inline int table_total_points(int B) { return 512 + B / 256 + 1024 + B; }
 
 hipError_t launch_fft_fwd(int B, bool irmode, const float *in, int64_t in_stride, int64_t in_len, c32 *Z, int T,
                           int nblocks, int njobs, const c32 *tables, hipStream_t s);
+void set_fwd_pair(bool on);  // forward transform form: two segments per workgroup (default) or one
 hipError_t launch_fft_inv(int B, const c32 *W, int T, int njobs, float *out, int64_t out_stride, int64_t out_len,
                           const float *prev, int64_t prev_stride, int64_t prev_len, const c32 *tables, hipStream_t s);
 hipError_t launch_hpack(const c32 *Zir, c32 *Hc, const c32 *wbin, int B, int P, int Pp, int nch, hipStream_t s);

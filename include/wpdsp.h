@@ -309,6 +309,7 @@ double wp_bpm_from_beat_rate(double sample_rate, int64_t beat_rate);
 #define WP_TUNE_PARTITION 0 /* partition size B: 1024, 2048, 4096 or 8192 */
 #define WP_TUNE_MAC_GROUP 1 /* partitions per multiply-accumulate pass: 4, 8, 12, 16, 24 */
 #define WP_TUNE_MAC_FORM 2  /* 1 streaming delay-line kernel, 2 small-batch gather kernel */
+#define WP_TUNE_FWD_FORM 4  /* forward transform: 1 one segment per workgroup, 2 two (the default; takes effect at once) */
 #define WP_TUNE_POOL_MB 3   /* cap of the wp_buf recycling pool in MiB (default 2048; 0 disables it) */
 int wp_tune(int what, int64_t value);
 

@@ -37,7 +37,7 @@ for f in sorted(glob.glob(os.path.join(root, "stats", "**", "*kernel_trace.csv")
         for row in csv.DictReader(fh):
             per[short(row["Kernel_Name"])].append((int(row["Start_Timestamp"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
     for k, v in per.items():
-        if not any(t in k for t in ("k_fft_fwd<", "k_fft_inv", "k_mac", "k_mix<")) or len(v) <= WARM:
+        if not any(t in k for t in ("k_fft_fwd<", "k_fft_fwd_pair<", "k_fft_inv", "k_mac", "k_mix<")) or len(v) <= WARM:
             continue
         d = [x[1] for x in sorted(v)]
         print("%-42s %s  -> steady avg %10.1f us" % (k, " ".join("%.0f" % x for x in d), sum(d[WARM:]) / len(d[WARM:])))
@@ -64,6 +64,8 @@ import json
 traffic = {}
 for k in acc:
     base = k.split("<")[0]
+    if base == "k_fft_fwd_pair":  # the forward transform of the bench path (two segments per workgroup)
+        base = "k_fft_fwd"
     if base == "k_fft_inv_mix":
         base = "k_fft_inv_mix_w" if "true" in k else "k_fft_inv_mix"
     if base in ("k_fft_fwd", "k_mac", "k_fft_inv", "k_fft_inv_mix", "k_fft_inv_mix_w", "k_mix") and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
