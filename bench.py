@@ -295,15 +295,20 @@ def main():
     fused = a.path == "fused"
     onepass = a.path == "onepass"
     out = None if fused else w.alloc_out(torch)
+    # which form of the convolution the library picked for these sizes: the partitioned one (forward
+    # transforms, multiply-accumulate over IR partitions, inverse transforms) or the long-frame one
+    # (column pass, row pass with the spectral product, inverse column pass)
+    lf = int(capi.lib().wp_conv_info(conv.handle, 6)) == 1
+    k1n, k2n, k3n = ("k_lf_fwd", "k_lf_mid", "k_lf_inv") if lf else ("k_fft_fwd", "k_mac", "k_fft_inv")
     if fused:
-        kern_ms = {"k_fft_fwd": 0.0, "k_mac": 0.0, "k_fft_inv_mix": 0.0}
+        kern_ms = {k1n: 0.0, k2n: 0.0, k3n + "_mix": 0.0}
     elif onepass:
-        kern_ms = {"k_fft_fwd": 0.0, "k_mac": 0.0, "k_fft_inv_mix_w": 0.0}
+        kern_ms = {k1n: 0.0, k2n: 0.0, k3n + "_mix_w": 0.0}
     else:
         mix = dev.DeviceMix([{"ch": [out[2 * t], out[2 * t + 1]], "rl": F, "sl": F, "vol": vol[t], "o": 0}
                              for t in range(tracks)])
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        kern_ms = {"k_fft_fwd": 0.0, "k_mac": 0.0, "k_fft_inv": 0.0, "k_mix": 0.0}
+        kern_ms = {k1n: 0.0, k2n: 0.0, k3n: 0.0, "k_mix": 0.0}
     conv.profile(True)
     counter = [0]
 
@@ -340,15 +345,15 @@ def main():
         reduce_bus(k)
         if timed and which == "main":
             f, m, i = conv.profile_read()
-            kern_ms["k_fft_fwd"] += f
-            kern_ms["k_mac"] += m
+            kern_ms[k1n] += f
+            kern_ms[k2n] += m
             if fused:
-                kern_ms["k_fft_inv_mix"] += i
+                kern_ms[k3n + "_mix"] += i
             elif onepass:
-                kern_ms["k_fft_inv_mix_w"] += i
+                kern_ms[k3n + "_mix_w"] += i
             else:
                 ev[1].synchronize()
-                kern_ms["k_fft_inv"] += i
+                kern_ms[k3n] += i
                 kern_ms["k_mix"] += ev[0].elapsed_time(ev[1])
 
     dt = time_steps(step, a.warmup, a.steps)
@@ -375,6 +380,9 @@ def main():
     B = int(capi.lib().wp_conv_info(conv.handle, 2))
     T = int(capi.lib().wp_conv_info(conv.handle, 1))
     P = int(capi.lib().wp_conv_info(conv.handle, 3))
+    N2 = int(capi.lib().wp_conv_info(conv.handle, 7)) if lf else 0
+    nfr = int(capi.lib().wp_conv_info(conv.handle, 8)) if lf else 0
+    hop = int(capi.lib().wp_conv_info(conv.handle, 9)) if lf else 1
 
     # secondary measurement for multi-GPU runs: the 2048-track render's per-GPU share (4 s IR per job)
     c5_extra = None
@@ -411,7 +419,14 @@ def main():
         Tout = (F + B - 1) // B if fused else T
         Tin = min(Tout, (F + B - 1) // B + 1)
         # algorithmic bytes per launch: every operand of the kernel read or written exactly once
+        # long-frame form: frames of N2 samples = Nc complex points, advancing by hop
+        nfr_run = (F + hop - 1) // hop if fused else nfr
         alg = {
+            "k_lf_fwd": njobs * (4 * F + 8 * (N2 // 2) * nfr_run),
+            "k_lf_mid": njobs * 16 * (N2 // 2) * nfr_run,
+            "k_lf_inv": njobs * (8 * (N2 // 2) * nfr + 4 * out_len),
+            "k_lf_inv_mix": njobs * 8 * (N2 // 2) * nfr_run + 2 * 2 * 4 * F,
+            "k_lf_inv_mix_w": njobs * (8 * (N2 // 2) * nfr + 4 * out_len) + 2 * 2 * 4 * F,
             "k_fft_fwd": njobs * (4 * F + 8 * B * Tin),
             "k_mac": njobs * (8 * B * Tin + 8 * B * Tout),
             "k_fft_inv": njobs * (8 * B * T + 4 * out_len),
@@ -440,7 +455,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "batched reverb+mix: %d stereo tracks/GPU x %.0f s @ %d Hz x %s, "
                                    "one go() per channel-job then mixBuffers into a stereo bus" % (tracks, a.seconds, a.rate, ir_desc),
-                       "name": a.config, "tracks_per_gpu": tracks, "frames": F, "ir_len": M, "partition": B, "partitions": P, "blocks": T,
+                       "name": a.config, "tracks_per_gpu": tracks, "frames": F, "ir_len": M, "form": ("long-frame overlap-save: %d frames of %d samples per job, hop %d" % (nfr, N2, hop)) if lf
+                       else ("partitioned overlap-save: %d partitions of %d, %d blocks per job" % (P, B, T)),
+                       "partition": B, "partitions": P, "blocks": T,
                        "path": {"fused": "wp_conv_mix_run_dev (bus only)", "onepass": "wp_conv_run_mix_dev (all go() results + bus in one pass)",
                                 "twopass": "wp_conv_run_dev + wp_mix_dev"}[a.path],
                        "parallelism": "tracks sharded over %d GPU(s); bus reduce: %s" % (world, reduce_kind)},

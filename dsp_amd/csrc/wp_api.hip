@@ -271,6 +271,75 @@ static int get_tables(int dev, int B, const c32 **out)
     return WP_OK;
 }
 
+static int g_tune_form = 0;  // WP_TUNE_CONV_FORM
+
+// per-(device, R) tables of the long-frame convolution (layout: wp_internal.h)
+static std::map<std::pair<int, int>, c32 *> g_lf_tables;
+
+static int get_lf_tables(int dev, int R, const c32 **out)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_pair(dev, R);
+    auto it = g_lf_tables.find(key);
+    if (it == g_lf_tables.end()) {
+        std::vector<c32> h(LF_TABLE_POINTS, c32{0.f, 0.f});
+        const double pi = 3.14159265358979323846;
+        const double Nc = (double)R * LF_C;
+        auto e = [](double turns) { return c32{(float)cos(2 * 3.14159265358979323846 * turns), (float)-sin(2 * 3.14159265358979323846 * turns)}; };
+        (void)pi;
+        for (int a = 0; a < 256; a++) h[LF_T256 + a] = e(a / 256.0);
+        for (int r = 0; r < R; r++) h[LF_ROW + r] = e(r / (2.0 * R));
+        for (int c = 0; c < LF_C; c++) h[LF_COL + c] = e(c / (2.0 * Nc));
+        for (int b = 0; b < 512; b++) h[LF_FLO + b] = e(b / Nc);
+        for (int a = 0; a < (int)(Nc / 512) && a < 1024; a++) h[LF_FHI + a] = e(a * 512.0 / Nc);
+        for (int k = 0; k < R; k++) h[LF_WA + k] = e((k + 0.5) / (2.0 * Nc));
+        for (int k = 0; k < LF_C; k++) h[LF_WB + k] = e(k / (2.0 * LF_C));
+        c32 *d = nullptr;
+        HIPCHK(hipMalloc((void **)&d, sizeof(c32) * LF_TABLE_POINTS));
+        HIPCHK(hipMemcpy(d, h.data(), sizeof(c32) * LF_TABLE_POINTS, hipMemcpyHostToDevice));
+        it = g_lf_tables.emplace(key, d).first;
+    }
+    *out = it->second;
+    return WP_OK;
+}
+
+// Long-frame form (wp_longframe_kernels.hip) for results much longer than the impulse response:
+// frames of N2 = 2*R*LF_C samples advancing by hop = N2 - mpad.  Picks the frame size that moves
+// the fewest bytes (20 per frame sample + 4 per output sample, + 8 per frame point when every job
+// has a kernel spectrum of its own) and returns 0 unless that is clearly below the partitioned
+// form's 40 bytes per output sample.
+struct LfGeom {
+    int R = 0;  // 0: partitioned form
+    int nframes = 0;
+    int64_t hop = 0, mpad = 0;
+};
+static LfGeom choose_lf(int64_t L, int64_t M, int nch)
+{
+    LfGeom best;
+    if (g_tune_form == 1) return best;
+    const int64_t out_len = L + M;
+    double best_cost = 0.85 * 40.0 * (double)out_len;
+    if (g_tune_form == 2) best_cost = 1e300;
+    for (int R : {128, 256}) {
+        const int64_t N2 = 2 * (int64_t)R * LF_C;
+        const int64_t mpad = ((M - 1 + 63) / 64) * 64;
+        if (mpad > N2 / 2) continue;
+        const int64_t hop = N2 - mpad;
+        const int64_t nf = (out_len + hop - 1) / hop;
+        if (nf > 65535) continue;
+        double cost = (double)nf * (double)N2 * 20.0 + 4.0 * (double)out_len;
+        if (nch > 4) cost += (double)nf * (double)(N2 / 2) * 8.0;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best.R = R;
+            best.nframes = (int)nf;
+            best.hop = hop;
+            best.mpad = mpad;
+        }
+    }
+    return best;
+}
+
 // ---------------------------------------------------------------------------
 // Partition spectra built from host samples are shared between handles: every
 // worker thread that receives the same kernel object (lib/impulse-convolve.js:9-13
@@ -301,6 +370,10 @@ struct wp_ir {
     bool shared;       // Hp belongs to g_ir_cache[key]
     IrKey key;
     const c32 *tables;
+    LfGeom lf;             // long-frame geometry for results of L+M samples (lf.R == 0: not used)
+    c32 *lf_Hs;            // [nch][R][LF_C] real spectra of the zero-padded kernels, scaled; owned by this handle
+    const c32 *lf_tab;     // long-frame tables of lf.R
+    const c32 *lf_tab_row; // tables of the 2048-point row transforms
     int64_t bytes;
     wp_conv *single;   // lazily built 1-job plan for wp_convolve / wp_convolve_dev
     int single_ch;     // IR channel that plan currently names
@@ -321,6 +394,8 @@ struct wp_conv {
     int32_t *job_irch;  // device table of each job's IR channel; nullptr for one-job plans, whose
     int irch_all;       // channel travels as a launch argument (it changes from call to call)
     c32 *Z, *W;
+    bool lf;            // long-frame form: A holds [njobs][ir->lf.nframes][R][LF_C] instead of Z and W
+    c32 *A;
     // one stream at a time may use a plan (Z and W are shared by its calls): a call on a
     // different stream than the previous one first waits for that call's last kernel
     hipStream_t last_stream;
@@ -367,6 +442,10 @@ extern "C" int wp_tune(int what, int64_t value)
     case WP_TUNE_MAC_FORM:
         if (value < 0 || value > 2) break;
         g_tune_mac = (int)value;
+        return WP_OK;
+    case WP_TUNE_CONV_FORM:
+        if (value < 0 || value > 2) break;
+        g_tune_form = (int)value;
         return WP_OK;
     case WP_TUNE_FWD_FORM:
         if (value < 0 || value > 2) break;
@@ -425,11 +504,15 @@ static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, 
     ir->stage_in = ir->stage_out = nullptr;
     ir->Hp = nullptr;
     ir->shared = false;
+    ir->lf = choose_lf(L, M, nch);
+    ir->lf_Hs = nullptr;
+    ir->lf_tab = ir->lf_tab_row = nullptr;
     c32 *Zir = nullptr;
     auto bail = [&](const char *what, hipError_t e) {
         fail(WP_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
         if (Zir) (void)hipFree(Zir);
         if (ir->Hp) (void)hipFree(ir->Hp);
+        if (ir->lf_Hs) (void)hipFree(ir->lf_Hs);
         delete ir;
         return (wp_ir *)nullptr;
     };
@@ -439,6 +522,29 @@ static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, 
     }
     const size_t hbytes = sizeof(c32) * (size_t)nch * ir->Pp * ir->B;
     ir->bytes = (int64_t)hbytes;
+    if (ir->lf.R) {
+        // kernel spectra of the long-frame form: the kernels as one "frame" each, through the same
+        // column and row passes the signal takes
+        const size_t lbytes = sizeof(c32) * (size_t)nch * ir->lf.R * LF_C;
+        c32 *tmpA = nullptr;
+        hipError_t e = hipSuccess;
+        if (get_lf_tables(dev, ir->lf.R, &ir->lf_tab) != WP_OK || get_tables(dev, LF_C, &ir->lf_tab_row) != WP_OK) {
+            delete ir;
+            return nullptr;
+        }
+        if ((e = hipMalloc((void **)&ir->lf_Hs, lbytes)) == hipSuccess) e = hipMalloc((void **)&tmpA, lbytes);
+        if (e == hipSuccess) e = launch_lf_fwd(ir->lf.R, ir_dev, ch_stride, M, tmpA, 1, 1, nch, 0, 0, ir->lf_tab, s);
+        if (e == hipSuccess) e = launch_lf_mid(true, ir->lf.R, tmpA, ir->lf_Hs, nullptr, 0, 1, 1, nch, ir->lf_tab, ir->lf_tab_row, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (tmpA) (void)hipFree(tmpA);
+        if (e != hipSuccess) {
+            fail(WP_ERR_HIP, "long-frame kernel spectra: %s", hipGetErrorString(e));
+            if (ir->lf_Hs) (void)hipFree(ir->lf_Hs);
+            delete ir;
+            return nullptr;
+        }
+        ir->bytes += (int64_t)lbytes;
+    }
     if (hashes) {
         ir->key = IrKey{dev, nch, ir->B, M, L, hashes[0], hashes[1]};
         std::lock_guard<std::mutex> lk(g_mu);
@@ -547,6 +653,7 @@ extern "C" void wp_ir_destroy(wp_ir *ir)
     if (ir->wrap_lin) (void)hipFree(ir->wrap_lin);
     if (ir->stage_in) (void)hipFree(ir->stage_in);
     if (ir->stage_out) (void)hipFree(ir->stage_out);
+    if (ir->lf_Hs) (void)hipFree(ir->lf_Hs);
     if (ir->shared) {
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = g_ir_cache.find(ir->key);
@@ -572,6 +679,7 @@ extern "C" int64_t wp_ir_info(const wp_ir *ir, int which)
     case 5: return ir->L + ir->M;
     case 6: return wp_next_pot((int32_t)(ir->L + ir->M));
     case 7: return ir->bytes;
+    case 9: return ir->lf.R ? 2 * (int64_t)ir->lf.R * LF_C : 0;
     case 8: {
         if (!ir->shared) return 1;
         std::lock_guard<std::mutex> lk(g_mu);
@@ -583,7 +691,7 @@ extern "C" int64_t wp_ir_info(const wp_ir *ir, int which)
 }
 
 // ---------------------------------------------------------------------------
-static wp_conv *conv_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t out_len);
+static wp_conv *conv_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t out_len, bool allow_lf = true);
 
 extern "C" wp_conv *wp_conv_create(wp_ir *ir, int njobs, const int32_t *job_ch)
 {
@@ -620,6 +728,8 @@ static void plan_geometry(wp_conv *c, wp_ir *ir, int njobs, int64_t out_len)
     c->job_irch = nullptr;
     c->irch_all = 0;
     c->Z = c->W = nullptr;
+    c->lf = false;
+    c->A = nullptr;
     c->bytes = 0;
     c->prof = c->prof_valid = false;
     for (auto &e : c->ev) e = nullptr;
@@ -629,7 +739,7 @@ static void plan_geometry(wp_conv *c, wp_ir *ir, int njobs, int64_t out_len)
     c->done = nullptr;
 }
 
-static wp_conv *conv_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t out_len)
+static wp_conv *conv_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t out_len, bool allow_lf)
 {
     if (need_device()) return nullptr;
     if (!ir || njobs < 1 || njobs > 65535 || !job_ch) {
@@ -651,15 +761,21 @@ static wp_conv *conv_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t
         e = hipMalloc((void **)&c->job_irch, sizeof(int32_t) * njobs);
         if (e == hipSuccess) e = hipMemcpy(c->job_irch, job_ch, sizeof(int32_t) * njobs, hipMemcpyHostToDevice);
     }
-    if (e == hipSuccess) e = hipMalloc((void **)&c->Z, sbytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->W, sbytes);
+    c->lf = allow_lf && ir->lf.R && out_len == ir->L + ir->M;
+    const size_t abytes = c->lf ? sizeof(c32) * (size_t)njobs * ir->lf.nframes * ir->lf.R * LF_C : 0;
+    if (c->lf) {
+        if (e == hipSuccess) e = hipMalloc((void **)&c->A, abytes);
+    } else {
+        if (e == hipSuccess) e = hipMalloc((void **)&c->Z, sbytes);
+        if (e == hipSuccess) e = hipMalloc((void **)&c->W, sbytes);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
     if (e != hipSuccess) {
-        fail(WP_ERR_HIP, "wp_conv_create: allocating %zu bytes of spectra failed: %s", 2 * sbytes, hipGetErrorString(e));
+        fail(WP_ERR_HIP, "wp_conv_create: allocating %zu bytes of spectra failed: %s", c->lf ? abytes : 2 * sbytes, hipGetErrorString(e));
         wp_conv_destroy(c);
         return nullptr;
     }
-    c->bytes = (int64_t)(2 * sbytes + (c->job_irch ? sizeof(int32_t) * njobs : 0));
+    c->bytes = (int64_t)((c->lf ? abytes : 2 * sbytes) + (c->job_irch ? sizeof(int32_t) * njobs : 0));
     return c;
 }
 
@@ -669,6 +785,7 @@ extern "C" void wp_conv_destroy(wp_conv *c)
     if (c->job_irch) (void)hipFree(c->job_irch);
     if (c->Z) (void)hipFree(c->Z);
     if (c->W) (void)hipFree(c->W);
+    if (c->A) (void)hipFree(c->A);
     if (c->vol_dev) (void)hipFree(c->vol_dev);
     if (c->done) (void)hipEventDestroy(c->done);
     for (auto &e : c->ev)
@@ -705,6 +822,10 @@ extern "C" int64_t wp_conv_info(const wp_conv *c, int which)
     case 3: return c->ir->Pp;
     case 4: return c->tchunk;
     case 5: return c->gather ? 1 : 0;
+    case 6: return c->lf ? 1 : 0;
+    case 7: return c->lf ? 2 * (int64_t)c->ir->lf.R * LF_C : 0;
+    case 8: return c->lf ? c->ir->lf.nframes : 0;
+    case 9: return c->lf ? c->ir->lf.hop : 0;
     }
     return WP_ERR_INVALID;
 }
@@ -748,6 +869,20 @@ static int check_in_len(const wp_ir *ir, int64_t in_len, bool wrap_ok = false)
 }
 
 // forward FFTs + spectral MAC for output blocks [0, Tout); leaves W ready
+// long-frame form: column pass + row pass for the first frames_run frames; leaves A ready for launch_lf_inv
+static int conv_front_lf(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len, int frames_run, hipStream_t s)
+{
+    const wp_ir *ir = c->ir;
+    if (c->prof) HIPCHK(hipEventRecord(c->ev[0], s));
+    HIPCHK(launch_lf_fwd(ir->lf.R, in_dev, in_stride, in_len, c->A, ir->lf.nframes, frames_run, c->njobs, ir->lf.hop, ir->lf.mpad,
+                         ir->lf_tab, s));
+    if (c->prof) HIPCHK(hipEventRecord(c->ev[1], s));
+    HIPCHK(launch_lf_mid(false, ir->lf.R, c->A, ir->lf_Hs, c->job_irch, c->irch_all, ir->lf.nframes, frames_run, c->njobs,
+                         ir->lf_tab, ir->lf_tab_row, s));
+    if (c->prof) HIPCHK(hipEventRecord(c->ev[2], s));
+    return WP_OK;
+}
+
 static int conv_front(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len, int Tout, hipStream_t s)
 {
     const wp_ir *ir = c->ir;
@@ -780,10 +915,17 @@ extern "C" int wp_conv_run_dev(wp_conv *c, const float *in_dev, int64_t in_strid
     if (int rc = check_in_len(ir, in_len, c->out_len != ir->L + ir->M)) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (int rc = plan_enter(c, s)) return rc;
-    if (int rc = conv_front(c, in_dev, in_stride, in_len, c->T, s)) return rc;
     if (prev_dev && prev_len > c->out_len) prev_len = c->out_len;
-    HIPCHK(launch_fft_inv(ir->B, c->W, c->T, c->njobs, out_dev, out_stride, c->out_len,
-                          prev_len > 0 ? prev_dev : nullptr, prev_stride, prev_len, ir->tables, s));
+    if (c->lf) {
+        if (int rc = conv_front_lf(c, in_dev, in_stride, in_len, ir->lf.nframes, s)) return rc;
+        HIPCHK(launch_lf_inv(ir->lf.R, c->A, ir->lf.nframes, ir->lf.nframes, c->njobs, ir->lf.hop, ir->lf.mpad, 0, nullptr, nullptr, 0,
+                             nullptr, out_dev, out_stride, c->out_len, ir->lf_tab, s));
+        if (prev_dev && prev_len > 0) HIPCHK(launch_add_prev(out_dev, out_stride, prev_dev, prev_stride, prev_len, c->njobs, s));
+    } else {
+        if (int rc = conv_front(c, in_dev, in_stride, in_len, c->T, s)) return rc;
+        HIPCHK(launch_fft_inv(ir->B, c->W, c->T, c->njobs, out_dev, out_stride, c->out_len,
+                              prev_len > 0 ? prev_dev : nullptr, prev_stride, prev_len, ir->tables, s));
+    }
     if (c->prof) {
         HIPCHK(hipEventRecord(c->ev[3], s));
         c->prof_valid = true;
@@ -812,11 +954,19 @@ static int conv_mix_common(wp_conv *c, const float *in_dev, int64_t in_stride, i
         HIPCHK(hipMemcpyAsync(c->vol_dev, vol, sizeof(double) * nsrc, hipMemcpyHostToDevice, s));
         c->vol_host.assign(vol, vol + nsrc);
     }
-    // with per-job results every output block is needed; otherwise only those that reach the bus
-    const int Tout = out_dev ? c->T : (int)((tl + ir->B - 1) / ir->B);
-    if (int rc = conv_front(c, in_dev, in_stride, in_len, Tout, s)) return rc;
-    HIPCHK(launch_fft_inv_mix(ir->B, c->W, c->T, Tout, nsrc, tgt_dev[0], tgt_dev[1], tl, c->vol_dev, out_dev, out_stride,
-                              ir->L + ir->M, ir->tables, s));
+    if (c->lf) {
+        // with per-job results every frame is needed; otherwise only those that reach the bus
+        const int frames_run = out_dev ? ir->lf.nframes : (int)((tl + ir->lf.hop - 1) / ir->lf.hop);
+        if (int rc = conv_front_lf(c, in_dev, in_stride, in_len, frames_run, s)) return rc;
+        HIPCHK(launch_lf_inv(ir->lf.R, c->A, ir->lf.nframes, frames_run, c->njobs, ir->lf.hop, ir->lf.mpad, nsrc, tgt_dev[0],
+                             tgt_dev[1], tl, c->vol_dev, out_dev, out_stride, ir->L + ir->M, ir->lf_tab, s));
+    } else {
+        // with per-job results every output block is needed; otherwise only those that reach the bus
+        const int Tout = out_dev ? c->T : (int)((tl + ir->B - 1) / ir->B);
+        if (int rc = conv_front(c, in_dev, in_stride, in_len, Tout, s)) return rc;
+        HIPCHK(launch_fft_inv_mix(ir->B, c->W, c->T, Tout, nsrc, tgt_dev[0], tgt_dev[1], tl, c->vol_dev, out_dev, out_stride,
+                                  ir->L + ir->M, ir->tables, s));
+    }
     if (c->prof) {
         HIPCHK(hipEventRecord(c->ev[3], s));
         c->prof_valid = true;
@@ -905,7 +1055,7 @@ extern "C" int wp_convolve_dev_noalloc(wp_ir *ir, int ch, const float *in_dev, i
     if (ch < 0 || ch >= ir->nch) return fail(WP_ERR_INVALID, "wp_convolve_dev_noalloc: IR channel %d of %d", ch, ir->nch);
     if (int rc = check_in_len(ir, in_len)) return rc;  // inputs that wrap in the reference's FFT: wp_convolve_dev
     wp_conv plan;
-    plan_geometry(&plan, ir, 1, ir->L + ir->M);
+    plan_geometry(&plan, ir, 1, ir->L + ir->M);  // always the partitioned form (plan.lf stays false)
     const size_t sbytes = sizeof(c32) * (size_t)plan.T * ir->B;
     if (2 * sbytes > (size_t)WP_NOALLOC_WORKSPACE_BYTES)
         return fail(WP_ERR_RANGE,
@@ -1024,7 +1174,11 @@ extern "C" int wp_kernel_from_spectrum(const float *spectrum, int64_t N, int64_t
 extern "C" wp_reverb *wp_reverb_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t offset)
 {
     if (need_device()) return nullptr;
-    wp_conv *c = wp_conv_create(ir, njobs, job_ch);
+    if (!ir) {
+        fail(WP_ERR_INVALID, "wp_reverb_create: null IR");
+        return nullptr;
+    }
+    wp_conv *c = conv_create(ir, njobs, job_ch, ir->L + ir->M);
     if (!c) return nullptr;
     wp_reverb *r = new wp_reverb();
     r->conv = c;

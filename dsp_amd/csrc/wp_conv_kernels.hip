@@ -12,73 +12,9 @@
 
 #include "wp_fft.h"
 #include "wp_internal.h"
+#include "wp_kernel_common.h"
 
 namespace wp {
-
-// streaming accesses: every spectrum row is written once and read once by a later
-// kernel, tens of gigabytes apart, so it is marked non-temporal
-typedef float v2f __attribute__((ext_vector_type(2)));
-// (WP_PLAIN_SPECTRA builds them as plain accesses: an experiment switch for cache-resident chunked runs)
-__device__ __forceinline__ c32 ld_nt(const c32 *p)
-{
-#ifdef WP_PLAIN_SPECTRA
-    return *p;
-#else
-    const v2f t = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
-    return c32{t.x, t.y};
-#endif
-}
-__device__ __forceinline__ void st_nt(c32 *p, c32 v)
-{
-#ifdef WP_PLAIN_SPECTRA
-    *p = v;
-#else
-    v2f t;
-    t.x = v.x;
-    t.y = v.y;
-    __builtin_nontemporal_store(t, reinterpret_cast<v2f *>(p));
-#endif
-}
-
-// ---------------------------------------------------------------------------
-// Twiddle tables of a kernel.  COPY: staged into LDS by the workgroup (the fused inverse
-// kernel, whose register budget has no room for the global loads' latency); otherwise read
-// from global memory where they are (one lookup per butterfly and stage, served by L1/L2:
-// no staging pass at kernel start, 0.06 ms faster in the forward kernel).
-template <int B, bool COPY>
-__device__ __forceinline__ TwTables<B> load_tables(const c32 *__restrict__ g, c32 *tws, int tid)
-{
-    const c32 *base = g;
-    if constexpr (COPY) {
-        constexpr int NT = B / FftPlan<B>::PT;
-        constexpr int N = tw_table_points<B>();
-        for (int i = tid; i < N; i += NT) tws[i] = g[i];
-        base = tws;
-    }
-    TwTables<B> tw;
-    tw.t256 = base;
-    tw.tlo = base + 256;
-    tw.thi = base + 512;
-    return tw;
-}
-
-// All stages but the last store: stage 0 computes from registers, every later stage
-// exchanges through LDS; on return v holds the LAST stage's inputs already twiddled and
-// transformed (the caller stores them with stage_store<B, LAST, ...>).
-template <int B, bool INV>
-__device__ __forceinline__ void middle_stages(int tid, c32 *v, c32 *lds, const TwTables<B> &tw)
-{
-    constexpr int LAST = FftPlan<B>::NSTAGE - 1;
-    stage_compute<B, 0, INV>(tid, v, tw);
-    static_for<1, LAST + 1>([&](auto sc) {
-        constexpr int S = decltype(sc)::value;
-        stage_store<B, S - 1, INV>(tid, v, [&](int i, c32 val, int, int) { lds[lds_pad(i)] = val; });
-        __syncthreads();
-        stage_load<B, S>(tid, v, [&](int i) { return lds[lds_pad(i)]; });
-        if constexpr (S < LAST) __syncthreads();  // the next store reuses the buffer
-        stage_compute<B, S, INV>(tid, v, tw);
-    });
-}
 
 // ---------------------------------------------------------------------------
 // Forward: one workgroup = one 2B-sample segment of one job.
@@ -257,11 +193,6 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv(const c32 *__res
 // arithmetic (f64 multiply, f64 add, f32 round per source), so the bus is
 // bit-identical to mixing the unfused outputs.  The next job's spectrum is
 // loaded while the current one is transformed.
-__device__ __forceinline__ float mix_fold(float acc, float y, double vol)
-{
-    return (float)((double)acc + (double)y * vol);  // this file is built with -ffp-contract=off
-}
-
 // WRITE: also store every job's samples (the go() results, L+M per job) while folding.
 template <int B, bool WRITE>
 __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv_mix(const c32 *__restrict__ W, int T, int nsrc,

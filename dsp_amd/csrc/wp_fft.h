@@ -137,6 +137,18 @@ struct Dft<4, INV> {
 // runs PT/R butterflies per thread.
 template <int B>
 struct FftPlan;
+// 128 and 256 points: the strided (column) transforms of the long-frame convolution; 8 or 16
+// threads of 16 points per transform, one exchange
+template <>
+struct FftPlan<128> {
+    static constexpr int PT = 16, NSTAGE = 2;
+    static constexpr int radix(int s) { return s == 0 ? 16 : 8; }
+};
+template <>
+struct FftPlan<256> {
+    static constexpr int PT = 16, NSTAGE = 2;
+    static constexpr int radix(int) { return 16; }
+};
 template <>
 struct FftPlan<1024> {
     static constexpr int PT = 16, NSTAGE = 3;

@@ -47,6 +47,31 @@ hipError_t launch_direct_conv(const float *x, int64_t n, const float *h, int64_t
 hipError_t launch_big_fft(const float *src, int64_t n_real, int64_t N, int inverse, void *work0, void *work1, float *dst,
                           int64_t n_out, hipStream_t s);
 
+// ---- long-frame convolution (wp_longframe_kernels.hip) ----
+// A frame of 2*Nc real samples = Nc = R*LF_C complex points; R = 128 or 256.
+constexpr int LF_C = 2048;
+// device table block of one R (c32 entries):
+//   [LF_T256, +256)  exp(-2*pi*i*a/256)            [LF_ROW, +256)   exp(-i*pi*r/R), r < R
+//   [LF_COL, +2048)  exp(-i*pi*c/Nc), c < LF_C     [LF_FLO, +512)   exp(-2*pi*i*b/Nc), b < 512
+//   [LF_FHI, +1024)  exp(-2*pi*i*a*512/Nc)         [LF_WA, +256)    exp(-i*pi*(k1+1/2)/Nc), k1 < R
+//   [LF_WB, +2048)   exp(-i*pi*k2/LF_C), k2 < LF_C
+constexpr int LF_T256 = 0, LF_ROW = 256, LF_COL = 512, LF_FLO = 2560, LF_FHI = 3072, LF_WA = 4096, LF_WB = 4352,
+              LF_TABLE_POINTS = 6400;
+// nframes: frames per job in A (the stride); frames_run <= nframes: how many of them this launch handles
+hipError_t launch_lf_fwd(int R, const float *in, int64_t in_stride, int64_t in_len, c32 *A, int nframes, int frames_run,
+                         int njobs, int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s);
+// tab_row: the table block of the 2048-point plan (row transforms)
+hipError_t launch_lf_mid(bool hprep, int R, c32 *A, c32 *Hs, const int32_t *job_irch, int irch_all, int nframes,
+                         int frames_run, int njobs, const c32 *tab, const c32 *tab_row, hipStream_t s);
+// bus0 == nullptr: plain results for every job; otherwise the bus fold over nsrc stereo sources (jobs 2s, 2s+1),
+// with the per-job results too when out != nullptr
+hipError_t launch_lf_inv(int R, const c32 *A, int nframes, int frames_run, int njobs, int64_t hop, int64_t mpad, int nsrc,
+                         float *bus0, float *bus1, int64_t tl, const double *vol, float *out, int64_t out_stride,
+                         int64_t out_len, const c32 *tab, hipStream_t s);
+// out[job][i] += prev[job][i], i < prev_len (the carried reverb tail, lib/impulse-reverb.js:14-16)
+hipError_t launch_add_prev(float *out, int64_t out_stride, const float *prev, int64_t prev_stride, int64_t prev_len, int njobs,
+                           hipStream_t s);
+
 size_t mix_scratch_bytes(int64_t nsrc);  // bytes of device scratch launch_mix needs
 hipError_t launch_mix(float *t0, float *t1, int tch, int64_t tl, const wp_src *srcs_dev, void *scratch,
                       int64_t nsrc, hipStream_t s);

@@ -1,0 +1,407 @@
+// wp_longframe_kernels.hip — long-frame overlap-save convolution for long inputs
+// (the GPU counterpart of one `go` of lib/convolve.js:564-586 when L is many times M).
+//
+// The partitioned form (wp_conv_kernels.hip) writes and reads a block spectrum of 8 bytes per
+// sample twice (Z and W): 40 bytes per output sample.  For inputs much longer than the impulse
+// response the same linear convolution is cheaper as overlap-save with frames of N2 = 2*Nc real
+// samples that each hold the WHOLE impulse response: a frame advances by hop = N2 - Mpad samples
+// (Mpad >= M-1) and costs 20 bytes per frame sample plus 4 per output sample, about 29 bytes per
+// output sample at N2 = 2^19, M = 96 000, and there is no multiply-accumulate over partitions.
+//
+// A frame is packed as Nc complex points z[m] = x[2m] + i x[2m+1], pre-twisted by exp(-i*pi*m/Nc)
+// (odd-frequency transform, wp_fft.h) and transformed by a four-step FFT, Nc = R * C, m = r*C + c:
+//   k_lf_fwd   R-point transforms down the columns (tiles of 32 columns x R rows, 256-byte runs),
+//              times exp(-2*pi*i*c*k1/Nc)                              -> A[k1][c]
+//   k_lf_mid   per row pair (k1, R-1-k1): C-point transform along the row gives bins k1 + R*k2;
+//              the partner bin Nc-1-k sits in the other row at C-1-k2, so the real/packed split,
+//              the product with the kernel spectrum, the unsplit and the inverse C-point
+//              transform all happen in one workgroup, in place
+//   k_lf_inv   conj twiddle, inverse R-point transforms down the columns, post-twist, the
+//              frame's last hop samples written out; with MIX the workgroup walks the sources
+//              in order and folds the samples into the master bus (src/mix-buffers.js:49-52)
+//              exactly as k_fft_inv_mix does.
+// All three are HBM-bound streaming kernels; nothing here is a dense contraction (no MFMA).
+#include <hip/hip_runtime.h>
+
+#include "wp_fft.h"
+#include "wp_internal.h"
+#include "wp_kernel_common.h"
+
+namespace wp {
+
+constexpr int LF_COLS = 32;  // columns per tile: 32 complex points = one 256-byte run per row
+
+// exp(-2*pi*i*idx/Nc), idx < Nc, from the two-level table (both factors correctly rounded)
+__device__ __forceinline__ c32 lf_w(const c32 *__restrict__ tab, int idx)
+{
+    return cmul(tab[LF_FHI + (idx >> 9)], tab[LF_FLO + (idx & 511)]);
+}
+
+// p[t] = w^t, t < N, by a product tree (each power at most log2(t) products from the lookup)
+template <int N>
+__device__ __forceinline__ void lf_powers(c32 w, c32 *p)
+{
+    p[0] = c32{1.0f, 0.0f};
+    p[1] = w;
+    static_for<2, N>([&](auto t) { p[t] = cmul(p[int(t) / 2], p[int(t) - int(t) / 2]); });
+}
+
+template <int R>
+__device__ __forceinline__ TwTables<R> lf_col_tables(const c32 *__restrict__ tab)
+{
+    TwTables<R> tw;  // every stage of a transform of at most 256 points looks up t256 only
+    tw.t256 = tab + LF_T256;
+    tw.tlo = tab + LF_T256;
+    tw.thi = tab + LF_T256;
+    return tw;
+}
+
+// ---------------------------------------------------------------------------
+// Forward column pass.  Workgroup = tile of 32 columns of one frame of one job; thread = (column,
+// j) with R/16 threads per column transform.  IRMODE: the "frame" is the impulse response itself,
+// starting at sample 0.
+template <int R>
+__global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_fwd(const float *__restrict__ in, int64_t in_stride, int64_t in_len,
+                                                            c32 *__restrict__ A, int nframes, int64_t hop, int64_t mpad,
+                                                            const c32 *__restrict__ tab)
+{
+    constexpr int C = LF_C, NTF = R / 16, PT = 16;
+    constexpr int64_t Nc = (int64_t)R * C;
+    extern __shared__ __align__(16) unsigned char smem[];
+    c32 *lds = reinterpret_cast<c32 *>(smem);
+    const int col = threadIdx.x & (LF_COLS - 1), j = threadIdx.x >> 5;
+    const int c = blockIdx.x * LF_COLS + col;
+    const int frame = blockIdx.y, job = blockIdx.z;
+    const TwTables<R> tw = lf_col_tables<R>(tab);
+    const float *x = in + (int64_t)job * in_stride;
+    const int64_t start = (int64_t)frame * hop - mpad;  // sample at frame position 0
+    const bool fast = start >= 0 && start + 2 * Nc <= in_len && ((reinterpret_cast<uintptr_t>(x + start) & 7) == 0);
+
+    c32 v[PT];
+    if (fast) {
+        const c32 *xs = reinterpret_cast<const c32 *>(x + start) + c;
+        static_for<0, PT>([&](auto t) { v[t] = xs[(int64_t)(j + int(t) * NTF) * C]; });
+    } else {
+        static_for<0, PT>([&](auto t) {
+            const int64_t g = start + 2 * ((int64_t)(j + int(t) * NTF) * C + c);
+            v[t].x = (g >= 0 && g < in_len) ? x[g] : 0.0f;
+            v[t].y = (g + 1 >= 0 && g + 1 < in_len) ? x[g + 1] : 0.0f;
+        });
+    }
+    // pre-twist exp(-i*pi*m/Nc), m = r*C + c, r = j + t*NTF:  exp(-i*pi*j/R) * exp(-i*pi*c/Nc) * exp(-i*pi*t/16)
+    {
+        const c32 f = cmul(tab[LF_ROW + j], tab[LF_COL + c]);
+        static_for<0, PT>([&](auto t) { v[t] = cmul(v[t], mul_w32<int(t), false>(f)); });
+    }
+    stage_compute<R, 0, false>(j, v, tw);
+    stage_store<R, 0, false>(j, v, [&](int i, c32 val, int, int) { lds[i * LF_COLS + col] = val; });
+    __syncthreads();
+    stage_load<R, 1>(j, v, [&](int i) { return lds[i * LF_COLS + col]; });
+    stage_compute<R, 1, false>(j, v, tw);
+    // outputs k1 = j' + 16*t (j' = j + u*NTF), times exp(-2*pi*i*c*k1/Nc) = W^(c*j') * (W^(16c))^t
+    constexpr int R1 = FftPlan<R>::radix(1), NB = PT / R1;
+    c32 pw[R1], wj[NB];
+    lf_powers<R1>(lf_w(tab, 16 * c), pw);
+    static_for<0, NB>([&](auto u) { wj[u] = lf_w(tab, c * (j + int(u) * NTF)); });
+    c32 *a = A + ((int64_t)job * nframes + frame) * Nc + c;
+    stage_store<R, 1, false>(j, v, [&](int k1, c32 val, auto t, auto u) {
+        st_nt(a + (int64_t)k1 * C, cmul(val, cmul(wj[u], pw[t])));
+    });
+}
+
+// ---------------------------------------------------------------------------
+// Row pass.  Workgroup = rows k1 and R-1-k1 of one frame of one job (256 threads: two C-point
+// transforms of 128 threads each).  HPREP: the rows are an impulse response's; store its real
+// spectrum scaled by 1/(8*Nc) (the factors 2 of split and unsplit and the inverse transform's Nc)
+// and stop.
+template <bool HPREP>
+__global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__restrict__ Hs, const int32_t *__restrict__ job_irch,
+                                                int irch_all, int R, int nframes, const c32 *__restrict__ tab,
+                                                const c32 *__restrict__ tab_row)
+{
+    constexpr int C = LF_C, NT = C / 16;
+    extern __shared__ __align__(16) unsigned char smem[];
+    c32 *lds = reinterpret_cast<c32 *>(smem);
+    c32 *tws = lds + 2 * C;  // unused: the row transform reads its tables from global memory
+    const int tid = threadIdx.x, half = tid >> 7, ft = tid & (NT - 1);
+    const int job = blockIdx.x, k1 = blockIdx.y, frame = blockIdx.z;  // jobs fastest: neighbours share the kernel spectrum rows
+    const int64_t Nc = (int64_t)R * C;
+    const int row = half ? R - 1 - k1 : k1;
+    c32 *rowp = A + (((int64_t)job * nframes + frame) * R + row) * C;
+    c32 *ldsrow = lds + half * C;
+    const TwTables<C> tw = load_tables<C, false>(tab_row, tws, ft);
+
+    c32 v[16];
+    stage_load<C, 0>(ft, v, [&](int n) { return ld_nt(rowp + n); });
+    middle_stages<C, false>(ft, v, ldsrow, tw);
+    __syncthreads();  // every lane has taken its last-stage inputs out of LDS
+    stage_store<C, FftPlan<C>::NSTAGE - 1, false>(ft, v, [&](int i, c32 val, int, int) { ldsrow[lds_pad(i)] = val; });
+    __syncthreads();
+
+    // bins k = k1 + R*k2 (row k1) and their partners Nc-1-k = (R-1-k1) + R*(C-1-k2) (the other row)
+    const int irch = HPREP ? job : (job_irch ? job_irch[job] : irch_all);
+    c32 *ha = Hs + ((int64_t)irch * R + k1) * C;
+    c32 *hb = Hs + ((int64_t)irch * R + (R - 1 - k1)) * C;
+    const c32 wa = tab[LF_WA + k1];
+    const float scale = 1.0f / (8.0f * (float)Nc);
+#pragma unroll
+    for (int q = 0; q < C / 256; q++) {
+        const int k2 = tid + 256 * q, p2 = C - 1 - k2;
+        const c32 za = lds[lds_pad(k2)], zb = lds[C + lds_pad(p2)];
+        const c32 wk = cmul(wa, tab[LF_WB + k2]);  // exp(-i*pi*(k+1/2)/Nc)
+        const c32 wp = c32{-wk.x, wk.y};          // the partner's: -conj(wk)
+        const c32 xa = bin_split(za, zb, wk), xb = bin_split(zb, za, wp);
+        if (HPREP) {
+            ha[k2] = c32{xa.x * scale, xa.y * scale};
+            hb[p2] = c32{xb.x * scale, xb.y * scale};
+        } else {
+            const c32 ya = cmul(xa, ha[k2]), yb = cmul(xb, hb[p2]);
+            lds[lds_pad(k2)] = bin_unsplit(ya, yb, wk);
+            lds[C + lds_pad(p2)] = bin_unsplit(yb, ya, wp);
+        }
+    }
+    if (HPREP) return;
+    __syncthreads();
+    stage_load<C, 0>(ft, v, [&](int n) { return ldsrow[lds_pad(n)]; });
+    __syncthreads();  // all stage-0 inputs are in registers before the first exchange overwrites the row
+    middle_stages<C, true>(ft, v, ldsrow, tw);
+    stage_store<C, FftPlan<C>::NSTAGE - 1, true>(ft, v, [&](int i, c32 val, int, int) { st_nt(rowp + i, val); });
+}
+
+// ---------------------------------------------------------------------------
+// Inverse column pass + output (+ master-bus fold).  MIX: workgroup = (tile, frame) of ONE bus
+// channel (blockIdx.z), walking the stereo sources in order (jobs 2s + channel) with the next
+// source's tile prefetched; otherwise blockIdx.z is the job.  WRITE: store the job's samples.
+template <int R, bool MIX, bool WRITE>
+__global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_inv(const c32 *__restrict__ A, int nframes, int64_t hop, int64_t mpad,
+                                                            int nsrc, float *__restrict__ bus0, float *__restrict__ bus1,
+                                                            int64_t tl, const double *__restrict__ vol, float *__restrict__ out,
+                                                            int64_t out_stride, int64_t out_len, const c32 *__restrict__ tab)
+{
+    constexpr int C = LF_C, NTF = R / 16, PT = 16;
+    constexpr int64_t Nc = (int64_t)R * C;
+    constexpr int R1 = FftPlan<R>::radix(1), NB = PT / R1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    c32 *lds = reinterpret_cast<c32 *>(smem);
+    const int col = threadIdx.x & (LF_COLS - 1), j = threadIdx.x >> 5;
+    const int c = blockIdx.x * LF_COLS + col;
+    const int frame = blockIdx.y;
+    const TwTables<R> tw = lf_col_tables<R>(tab);
+    // inputs k1 = j + t*NTF: conj of exp(-2*pi*i*c*k1/Nc) = conj(W^(c*j)) * conj(W^(c*NTF))^t
+    c32 tin[PT];
+    {
+        c32 pw[PT];
+        lf_powers<PT>(cconj(lf_w(tab, c * NTF)), pw);
+        const c32 w0 = cconj(lf_w(tab, c * j));
+        static_for<0, PT>([&](auto t) { tin[t] = cmul(w0, pw[t]); });
+    }
+    // outputs r = j' + 16*t (j' = j + u*NTF): post-twist exp(+i*pi*m/Nc), m = r*C + c
+    c32 pf[NB];
+    static_for<0, NB>([&](auto u) { pf[u] = cconj(cmul(tab[LF_ROW + j + int(u) * NTF], tab[LF_COL + c])); });
+    // sample pair of output (u, t): frame position 2m, kept when it lies in the frame's last hop samples
+    const int64_t obase = (int64_t)frame * hop - mpad + 2 * (int64_t)c;
+    auto out_index = [&](int r) { return obase + 2 * (int64_t)r * C; };  // global sample index (valid when >= frame*hop)
+    const int64_t first = (int64_t)frame * hop;
+
+    auto fetch = [&](int job, c32 *v) {
+        const c32 *a = A + ((int64_t)job * nframes + frame) * Nc + c;
+        static_for<0, PT>([&](auto t) { v[t] = ld_nt(a + (int64_t)(j + int(t) * NTF) * C); });
+    };
+    auto transform = [&](c32 *v) {
+        static_for<0, PT>([&](auto t) { v[t] = cmul(v[t], tin[t]); });
+        stage_compute<R, 0, true>(j, v, tw);
+        stage_store<R, 0, true>(j, v, [&](int i, c32 val, int, int) { lds[i * LF_COLS + col] = val; });
+        __syncthreads();
+        stage_load<R, 1>(j, v, [&](int i) { return lds[i * LF_COLS + col]; });
+        stage_compute<R, 1, true>(j, v, tw);
+    };
+
+    if constexpr (!MIX) {
+        const int job = blockIdx.z;
+        c32 v[PT];
+        fetch(job, v);
+        transform(v);
+        float *y = out + (int64_t)job * out_stride;
+        const bool al = (reinterpret_cast<uintptr_t>(y) & 7) == 0;  // the sample index is even
+        stage_store<R, 1, true>(j, v, [&](int r, c32 val, auto t, auto u) {
+            val = cmul(val, mul_w32<int(t) * (256 / R), true>(pf[u]));
+            const int64_t o = out_index(r);
+            if (o >= first) {
+                if (al && o + 1 < out_len) {
+                    st_nt(reinterpret_cast<c32 *>(y + o), val);
+                } else {
+                    if (o < out_len) y[o] = val.x;
+                    if (o + 1 < out_len) y[o + 1] = val.y;
+                }
+            }
+        });
+    } else {
+        const int ch = blockIdx.z;
+        float *__restrict__ bus = ch ? bus1 : bus0;
+        const bool bal = (reinterpret_cast<uintptr_t>(bus) & 7) == 0;
+        c32 acc[PT];
+        auto each_out = [&](auto &&f) {  // f(slot, global sample index) for every output of this thread
+            static_for<0, NB>([&](auto u) {
+                static_for<0, R1>([&](auto t) {
+                    f(ic<int(u) * R1 + int(t)>{}, out_index(j + int(u) * NTF + int(t) * 16));
+                });
+            });
+        };
+        each_out([&](auto slot, int64_t o) {
+            acc[slot] = c32{0.f, 0.f};
+            if (o >= first) {
+                if (bal && o + 1 < tl) {
+                    acc[slot] = *reinterpret_cast<const c32 *>(bus + o);
+                } else {
+                    if (o < tl) acc[slot].x = bus[o];
+                    if (o + 1 < tl) acc[slot].y = bus[o + 1];
+                }
+            }
+        });
+        auto transform_fold = [&](c32 *v, int src, double g) {
+            transform(v);
+            float *y = WRITE ? out + (int64_t)(2 * src + ch) * out_stride : nullptr;
+            const bool al = WRITE && (reinterpret_cast<uintptr_t>(y) & 7) == 0;
+            stage_store<R, 1, true>(j, v, [&](int r, c32 val, auto t, auto u) {
+                val = cmul(val, mul_w32<int(t) * (256 / R), true>(pf[u]));
+                const int64_t o = out_index(r);
+                if (o >= first) {
+                    if constexpr (WRITE) {
+                        if (al && o + 1 < out_len) {
+                            st_nt(reinterpret_cast<c32 *>(y + o), val);
+                        } else {
+                            if (o < out_len) y[o] = val.x;
+                            if (o + 1 < out_len) y[o + 1] = val.y;
+                        }
+                    }
+                    constexpr int slot = int(u) * R1 + int(t);
+                    acc[slot].x = mix_fold(acc[slot].x, val.x, g);
+                    acc[slot].y = mix_fold(acc[slot].y, val.y, g);
+                }
+            });
+            __syncthreads();  // every lane is done reading LDS before the next transform overwrites it
+        };
+        c32 v[PT], vn[PT];
+        fetch(ch, vn);
+#pragma unroll 1
+        for (int s = 0; s < nsrc; s++) {
+#pragma unroll
+            for (int i = 0; i < PT; i++) v[i] = vn[i];
+            fetch(2 * (s + 1 < nsrc ? s + 1 : nsrc - 1) + ch, vn);  // clamped: always a valid tile
+            transform_fold(v, s, vol[s]);
+        }
+        each_out([&](auto slot, int64_t o) {
+            if (o >= first) {
+                if (bal && o + 1 < tl) {
+                    *reinterpret_cast<c32 *>(bus + o) = acc[slot];
+                } else {
+                    if (o < tl) bus[o] = acc[slot].x;
+                    if (o + 1 < tl) bus[o + 1] = acc[slot].y;
+                }
+            }
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+template <class K>
+static hipError_t lf_lds(K kernel, size_t bytes)
+{
+    if (bytes <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <int R>
+static hipError_t lf_fwd_t(const float *in, int64_t in_stride, int64_t in_len, c32 *A, int nframes, int frames_run, int njobs,
+                           int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s)
+{
+    const size_t lds = sizeof(c32) * R * LF_COLS;
+    if (hipError_t e = lf_lds(k_lf_fwd<R>, lds)) return e;
+    hipLaunchKernelGGL((k_lf_fwd<R>), dim3(LF_C / LF_COLS, frames_run, njobs), dim3(LF_COLS * R / 16), lds, s, in, in_stride, in_len,
+                       A, nframes, hop, mpad, tab);
+    return hipGetLastError();
+}
+
+hipError_t launch_lf_fwd(int R, const float *in, int64_t in_stride, int64_t in_len, c32 *A, int nframes, int frames_run,
+                         int njobs, int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s)
+{
+    if (frames_run <= 0) return hipSuccess;
+    if (nframes > 65535 || njobs > 65535) return hipErrorInvalidValue;
+    switch (R) {
+    case 128: return lf_fwd_t<128>(in, in_stride, in_len, A, nframes, frames_run, njobs, hop, mpad, tab, s);
+    case 256: return lf_fwd_t<256>(in, in_stride, in_len, A, nframes, frames_run, njobs, hop, mpad, tab, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_lf_mid(bool hprep, int R, c32 *A, c32 *Hs, const int32_t *job_irch, int irch_all, int nframes,
+                         int frames_run, int njobs, const c32 *tab, const c32 *tab_row, hipStream_t s)
+{
+    if (frames_run <= 0) return hipSuccess;
+    const size_t lds = sizeof(c32) * 2 * LF_C;
+    const dim3 grid(njobs, R / 2, frames_run), block(256);
+    if (hprep)
+        hipLaunchKernelGGL((k_lf_mid<true>), grid, block, lds, s, A, Hs, job_irch, irch_all, R, nframes, tab, tab_row);
+    else
+        hipLaunchKernelGGL((k_lf_mid<false>), grid, block, lds, s, A, Hs, job_irch, irch_all, R, nframes, tab, tab_row);
+    return hipGetLastError();
+}
+
+template <int R>
+static hipError_t lf_inv_t(const c32 *A, int nframes, int frames_run, int njobs, int64_t hop, int64_t mpad, int nsrc, float *bus0, float *bus1,
+                           int64_t tl, const double *vol, float *out, int64_t out_stride, int64_t out_len, const c32 *tab,
+                           hipStream_t s)
+{
+    const size_t lds = sizeof(c32) * R * LF_COLS;
+    const dim3 block(LF_COLS * R / 16);
+    if (!bus0) {
+        if (hipError_t e = lf_lds(k_lf_inv<R, false, true>, lds)) return e;
+        hipLaunchKernelGGL((k_lf_inv<R, false, true>), dim3(LF_C / LF_COLS, frames_run, njobs), block, lds, s, A, nframes, hop, mpad,
+                           nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab);
+    } else if (out) {
+        if (hipError_t e = lf_lds(k_lf_inv<R, true, true>, lds)) return e;
+        hipLaunchKernelGGL((k_lf_inv<R, true, true>), dim3(LF_C / LF_COLS, frames_run, 2), block, lds, s, A, nframes, hop, mpad, nsrc,
+                           bus0, bus1, tl, vol, out, out_stride, out_len, tab);
+    } else {
+        if (hipError_t e = lf_lds(k_lf_inv<R, true, false>, lds)) return e;
+        hipLaunchKernelGGL((k_lf_inv<R, true, false>), dim3(LF_C / LF_COLS, frames_run, 2), block, lds, s, A, nframes, hop, mpad, nsrc,
+                           bus0, bus1, tl, vol, out, out_stride, out_len, tab);
+    }
+    return hipGetLastError();
+}
+
+// bus0 == nullptr: plain results for every job; otherwise the bus fold over nsrc stereo sources,
+// with the per-job results too when out != nullptr
+hipError_t launch_lf_inv(int R, const c32 *A, int nframes, int frames_run, int njobs, int64_t hop, int64_t mpad, int nsrc,
+                         float *bus0, float *bus1, int64_t tl, const double *vol, float *out, int64_t out_stride,
+                         int64_t out_len, const c32 *tab, hipStream_t s)
+{
+    if (frames_run <= 0) return hipSuccess;
+    if (nframes > 65535 || njobs > 65535) return hipErrorInvalidValue;
+    switch (R) {
+    case 128: return lf_inv_t<128>(A, nframes, frames_run, njobs, hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab, s);
+    case 256: return lf_inv_t<256>(A, nframes, frames_run, njobs, hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+__global__ void k_add_prev(float *__restrict__ out, int64_t out_stride, const float *__restrict__ prev, int64_t prev_stride,
+                           int64_t prev_len)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= prev_len) return;
+    const int job = blockIdx.y;
+    out[(int64_t)job * out_stride + i] += prev[(int64_t)job * prev_stride + i];
+}
+
+hipError_t launch_add_prev(float *out, int64_t out_stride, const float *prev, int64_t prev_stride, int64_t prev_len, int njobs,
+                           hipStream_t s)
+{
+    if (prev_len <= 0 || njobs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_add_prev, dim3((unsigned)((prev_len + 255) / 256), njobs), dim3(256), 0, s, out, out_stride, prev,
+                       prev_stride, prev_len);
+    return hipGetLastError();
+}
+
+}  // namespace wp

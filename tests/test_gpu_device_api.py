@@ -443,6 +443,66 @@ def test_fused_paths_vs_oracle_all_plans(torch, oracle, L, M, tracks, per_track_
     assert torch.equal(bus.view(torch.int32), bus2.view(torch.int32))
 
 
+@pytest.mark.parametrize("L,M,tracks,frame", [(600000, 5000, 2, 524288), (1300000, 96000, 1, 524288), (900000, 300000, 1, 1048576)])
+def test_long_frame_form_vs_oracle(torch, oracle, L, M, tracks, frame):
+    """The long-frame form of the convolution (whole impulse response per frame, four-step transform)
+    against the oracle: plain results with an odd output stride and a short input, the one-pass
+    results + bus, the bus-only entry point, and the bus against wp_mix_dev of the written results
+    bit for bit.  Frames of 2^19 and 2^20 samples (the second because M > 2^18)."""
+    from dsp_amd import capi, device
+    lib = capi.lib()
+    njobs = 2 * tracks
+    irs = np.stack([oracle.synth_ir(M, 800 + c) for c in range(2)])
+    capi.check(lib.wp_tune(5, 2), "wp_tune")  # WP_TUNE_CONV_FORM: long-frame where the sizes allow
+    try:
+        ir = device.DeviceIR(torch.from_numpy(irs).cuda(), L)
+    finally:
+        lib.wp_tune(5, 0)
+    assert ir.info(9) == frame
+    job_ch = [(j + 1) % 2 for j in range(njobs)]
+    conv = device.BatchedConvolver(ir, job_ch)
+    assert lib.wp_conv_info(conv.handle, 6) == 1 and lib.wp_conv_info(conv.handle, 7) == frame
+    x = np.stack([oracle.synth_noise(L, 900 + j) for j in range(njobs)])
+    xd = torch.from_numpy(x).cuda()
+    kern = [oracle.fft_process_kernel(L, irs[c]) for c in range(2)]
+    want = [oracle.fft_convolution(L, kern[job_ch[j]], M)(x[j]) for j in range(njobs)]
+    out = torch.full((njobs, L + M + 5), 7.0, dtype=torch.float32, device="cuda")  # odd stride: unaligned rows
+    conv.run(xd, out)
+    got = out.cpu().numpy()
+    for j in range(njobs):
+        err = float(np.abs(got[j, :L + M].astype(np.float64) - want[j]).max())
+        assert err <= TOL, (j, err)
+        assert (got[j, L + M:] == 7.0).all(), "wrote past L+M"
+    n_in = L // 3 + 1
+    conv.run(xd, out, in_len=n_in)
+    w0 = oracle.fft_convolution(L, kern[job_ch[0]], M)(x[0][:n_in])
+    assert float(np.abs(out[0, :L + M].cpu().numpy().astype(np.float64) - w0).max()) <= TOL
+    # one pass with the bus, and bus only
+    out2 = torch.full((njobs, L + M + 2), 3.0, dtype=torch.float32, device="cuda")
+    tl = L + M // 2
+    bus = torch.empty((2, tl), dtype=torch.float32, device="cuda")
+    device.synth_noise(bus[0], 5)
+    device.synth_noise(bus[1], 6)
+    bus0 = bus.clone()
+    bus2 = bus.clone()
+    bus3 = bus.clone()
+    vol = [0.75 / (s + 1) for s in range(tracks)]
+    conv.run_and_mix(xd, out2, [bus[0], bus[1]], vol)
+    conv.run_mix(xd, [bus2[0], bus2[1]], vol)
+    torch.cuda.synchronize()
+    got2 = out2.cpu().numpy()
+    for j in range(njobs):
+        assert float(np.abs(got2[j, :L + M].astype(np.float64) - want[j]).max()) <= TOL, j
+        assert (got2[j, L + M:] == 3.0).all()
+    assert torch.equal(bus.view(torch.int32), bus2.view(torch.int32))
+    device.DeviceMix([{"ch": [out2[2 * t], out2[2 * t + 1]], "rl": L + M, "sl": L + M, "vol": vol[t]} for t in range(tracks)]).run([bus3[0], bus3[1]])
+    assert torch.equal(bus.view(torch.int32), bus3.view(torch.int32))
+    want_bus = [bus0[0].cpu().numpy().copy(), bus0[1].cpu().numpy().copy()]
+    oracle.mix_buffers(want_bus, *[[[want[2 * s], want[2 * s + 1]], 1, vol[s], 0] for s in range(tracks)])
+    for ch in range(2):
+        assert float(np.abs(bus[ch].cpu().numpy().astype(np.float64) - want_bus[ch]).max()) <= TOL
+
+
 def test_mix_4096_aliased_stems_exact(torch):
     """The master reduce at its full source count: 4096 stereo sources (all views of one
     60 s stem, so the test holds 46 MB instead of 94 GB) with vol = 1/4096.  Samples with 11

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--tracks", type=int, default=256)
     ap.add_argument("--recreate", action="store_true", help="the knob only affects handles created afterwards")
+    ap.add_argument("--tol", type=float, default=0.0, help="allowed max abs difference between values (0: bit-identical)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -58,6 +59,7 @@ def main():
 
     res = {v: [] for v in values}
     ref = None
+    worst = 0.0
     for r in range(a.rounds + 1):
         for v in values:
             ir, conv = plan(v)
@@ -72,8 +74,11 @@ def main():
                 res[v].append(conv.profile_read() + (dt,))
             if ref is None:
                 ref = (bus.clone(), out[0].clone())
-            else:
+            elif a.tol == 0.0:
                 assert torch.equal(ref[0].view(torch.int32), bus.view(torch.int32)) and torch.equal(ref[1].view(torch.int32), out[0].view(torch.int32)), "results differ between knob values"
+            else:
+                worst = max(worst, float((ref[0] - bus).abs().max()), float((ref[1] - out[0]).abs().max()))
+                assert worst <= a.tol, "results differ by %.3e between knob values" % worst
             if a.recreate:
                 conv.close()
                 ir.close()
@@ -82,7 +87,7 @@ def main():
         cols = list(zip(*res[v]))
         print("knob %d = %d: " % (a.knob, v) + "  ".join("%s med %.3f min %.3f" % (n, statistics.median(c), min(c))
                                                           for n, c in zip(("fwd", "mac", "inv", "step"), cols)), flush=True)
-    print("results identical across values: True")
+    print("results identical across values: True" if a.tol == 0.0 else "max abs difference across values: %.3e" % worst)
 
 
 if __name__ == "__main__":

@@ -12,7 +12,7 @@ root = sys.argv[1]
 
 def short(name):
     n = name.split("(")[0]
-    for k in ("k_fft_fwd", "k_fft_inv", "k_mac", "k_mix_prep", "k_mix", "k_hpack", "k_synth_noise"):
+    for k in ("k_lf_fwd", "k_lf_mid", "k_lf_inv", "k_fft_fwd", "k_fft_inv", "k_mac", "k_mix_prep", "k_mix", "k_hpack", "k_synth_noise"):
         if k in n:
             t = n[n.index(k):]
             return t[:44]
@@ -37,7 +37,7 @@ for f in sorted(glob.glob(os.path.join(root, "stats", "**", "*kernel_trace.csv")
         for row in csv.DictReader(fh):
             per[short(row["Kernel_Name"])].append((int(row["Start_Timestamp"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
     for k, v in per.items():
-        if not any(t in k for t in ("k_fft_fwd<", "k_fft_fwd_pair<", "k_fft_inv", "k_mac", "k_mix<")) or len(v) <= WARM:
+        if not any(t in k for t in ("k_lf_", "k_fft_fwd<", "k_fft_fwd_pair<", "k_fft_inv", "k_mac", "k_mix<")) or len(v) <= WARM:
             continue
         d = [x[1] for x in sorted(v)]
         print("%-42s %s  -> steady avg %10.1f us" % (k, " ".join("%.0f" % x for x in d), sum(d[WARM:]) / len(d[WARM:])))
@@ -68,10 +68,15 @@ for k in acc:
         base = "k_fft_fwd"
     if base == "k_fft_inv_mix":
         base = "k_fft_inv_mix_w" if "true" in k else "k_fft_inv_mix"
-    if base in ("k_fft_fwd", "k_mac", "k_fft_inv", "k_fft_inv_mix", "k_fft_inv_mix_w", "k_mix") and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
+    if base == "k_lf_inv":  # k_lf_inv<R, MIX, WRITE>
+        flags = k.replace(" ", "").split(",")[1:3]
+        base = "k_lf_inv" + ("_mix" if flags and flags[0].startswith("true") else "") + ("_w" if len(flags) > 1 and flags[0].startswith("true") and flags[1].startswith("true") else "")
+    if base == "k_lf_mid" and "true" in k:
+        continue  # the one-off kernel-spectrum launch
+    if base in ("k_lf_fwd", "k_lf_mid", "k_lf_inv", "k_lf_inv_mix", "k_lf_inv_mix_w", "k_fft_fwd", "k_mac", "k_fft_inv", "k_fft_inv_mix", "k_fft_inv_mix_w", "k_mix") and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
         f = acc[k]["FETCH_SIZE"][0] / acc[k]["FETCH_SIZE"][1]
         w = acc[k]["WRITE_SIZE"][0] / acc[k]["WRITE_SIZE"][1]
-        if base == "k_fft_fwd" and f < 1e5:
+        if base in ("k_fft_fwd", "k_lf_fwd") and f < 1e5:
             continue  # the one-off IR-partition launch, not the bench kernel
         traffic[base] = int(2 * f * 1024 + w * 1024)
 print("# traffic bytes per launch (2*FETCH_SIZE + WRITE_SIZE):", traffic)
