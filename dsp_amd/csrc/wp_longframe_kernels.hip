@@ -164,8 +164,10 @@ __global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__rest
     __syncthreads();
     stage_load<C, 0>(ft, v, [&](int n) { return ldsrow[lds_pad(n)]; });
     __syncthreads();  // all stage-0 inputs are in registers before the first exchange overwrites the row
-    middle_stages<C, true>(ft, v, ldsrow, tw);
-    stage_store<C, FftPlan<C>::NSTAGE - 1, true>(ft, v, [&](int i, c32 val, int, int) { st_nt(rowp + i, val); });
+    int fi = ft;  // hidden from the optimiser, which would otherwise keep the forward transform's twiddle powers alive for the inverse (119 instead of 76 registers)
+    asm volatile("" : "+v"(fi));
+    middle_stages<C, true>(fi, v, ldsrow, tw);
+    stage_store<C, FftPlan<C>::NSTAGE - 1, true>(fi, v, [&](int i, c32 val, int, int) { st_nt(rowp + i, val); });
 }
 
 // ---------------------------------------------------------------------------
