@@ -423,7 +423,8 @@ def main():
         nfr_run = (F + hop - 1) // hop if fused else nfr
         alg = {
             "k_lf_fwd": njobs * (4 * F + 8 * (N2 // 2) * nfr_run),
-            "k_lf_mid": njobs * 16 * (N2 // 2) * nfr_run,
+            # (+ 8 bytes per frame point when every job has a kernel spectrum of its own to read)
+            "k_lf_mid": njobs * (16 + (8 if a.config == "c5" else 0)) * (N2 // 2) * nfr_run,
             "k_lf_inv": njobs * (8 * (N2 // 2) * nfr + 4 * out_len),
             "k_lf_inv_mix": njobs * 8 * (N2 // 2) * nfr_run + 2 * 2 * 4 * F,
             "k_lf_inv_mix_w": njobs * (8 * (N2 // 2) * nfr + 4 * out_len) + 2 * 2 * 4 * F,

@@ -133,15 +133,15 @@ __global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__rest
 
     c32 v[16];
     stage_load<C, 0>(ft, v, [&](int n) { return ld_nt(rowp + n); });
+    const int irch = HPREP ? job : (job_irch ? job_irch[job] : irch_all);
+    c32 *ha = Hs + ((int64_t)irch * R + k1) * C;
+    c32 *hb = Hs + ((int64_t)irch * R + (R - 1 - k1)) * C;
     middle_stages<C, false>(ft, v, ldsrow, tw);
     __syncthreads();  // every lane has taken its last-stage inputs out of LDS
     stage_store<C, FftPlan<C>::NSTAGE - 1, false>(ft, v, [&](int i, c32 val, int, int) { ldsrow[lds_pad(i)] = val; });
     __syncthreads();
 
     // bins k = k1 + R*k2 (row k1) and their partners Nc-1-k = (R-1-k1) + R*(C-1-k2) (the other row)
-    const int irch = HPREP ? job : (job_irch ? job_irch[job] : irch_all);
-    c32 *ha = Hs + ((int64_t)irch * R + k1) * C;
-    c32 *hb = Hs + ((int64_t)irch * R + (R - 1 - k1)) * C;
     const c32 wa = tab[LF_WA + k1];
     const float scale = 1.0f / (8.0f * (float)Nc);
 #pragma unroll
