@@ -76,6 +76,14 @@ def test_reference_layout_kernels_at_config_size(wp, oracle):
     assert_bits_equal(wp.convolve.direct_convolution(xs, hs), oracle.direct_convolution(xs, hs).view(np.uint32), "direct 5000 x 3000")
 
 
+def test_integer_helpers_on_the_gpu_box(wp):
+    """The bit-exact integer contract (nextPowerOfTwo, beat rate and bpm getter, ring index, (rl*length)|0)
+    against the reference's vectors, run on the GPU box as well as in the CPU suite."""
+    from test_boundary_cpu import test_integer_helpers_match_reference_vectors, test_reverb_view_arithmetic_matches_reference_blocks
+    test_integer_helpers_match_reference_vectors()
+    test_reverb_view_arithmetic_matches_reference_blocks()
+
+
 def test_error_behaviour(wp):
     k = wp.convolve.fft_process_kernel(4, np.ones(4, np.float32))
     go = wp.convolve.fft_convolution(4, k, 4)
