@@ -233,6 +233,7 @@ def main():
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     comm = None
+    rccl_group = None
     reduce_kind = "none (one rank)"
     if world > 1:
         if a.reduce == "capi":
@@ -243,13 +244,30 @@ def main():
             sys.stdout.flush()
             saved = os.dup(1)
             os.dup2(2, 1)
+            why = ""
             try:
                 comm = dev.Comm(rank, world, dev.gloo_rendezvous(dist))
+            except Exception as e:
+                why = "%s: %s" % (type(e).__name__, e)
+                print("[bench] rank %d: wp_comm_create failed: %s" % (rank, why), file=sys.stderr, flush=True)
             finally:
                 sys.stdout.flush()
                 os.dup2(saved, 1)
                 os.close(saved)
-            reduce_kind = "wp_bus_reduce: ncclReduce(sum, f32) through the C ABI (%s), side stream, two bus buffers" % os.path.basename(comm.library)
+            # every rank must take the same road: if the communicator is missing anywhere, all ranks fall back to
+            # torch.distributed's own RCCL group for the reduce and the JSON line says so
+            flag = torch.tensor([0.0 if comm is None else 1.0], dtype=torch.float64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if flag.item() == 1.0:
+                reduce_kind = ("wp_bus_reduce: ncclReduce(sum, f32) through the C ABI (%s), side stream, two bus buffers"
+                               % os.path.basename(comm.library))
+            else:
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                rccl_group = dist.new_group(backend="nccl")
+                reduce_kind = ("torch.distributed.reduce (nccl group) -- FALLBACK: wp_comm_create failed on at least one rank%s"
+                               % ((" (%s)" % why[:200]) if why else ""))
         elif a.backend == "nccl":
             try:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -324,7 +342,7 @@ def main():
             e.record(side)
             reduced[k] = e
         else:
-            dev.reduce_master_bus(bus, dist, dst=0)
+            dev.reduce_master_bus(bus, dist, dst=0, group=rccl_group)
 
     def step(timed, which="main"):
         k = counter[0] % len(buses)

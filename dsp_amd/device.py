@@ -191,13 +191,22 @@ class Comm:
         capi.init()
         L = capi.lib()
         idb = (C.c_ubyte * 128)()
+        if world > 1 and rendezvous is None:
+            raise ValueError("more than one rank needs a rendezvous callable to pass the id")
+        why = None
         if rank == 0:
-            capi.check(L.wp_comm_unique_id(idb), "wp_comm_unique_id")
+            try:
+                capi.check(L.wp_comm_unique_id(idb), "wp_comm_unique_id")
+            except Exception as e:  # the other ranks are waiting in the rendezvous: release them with an all-zero id
+                why = e
+                idb = (C.c_ubyte * 128)()
         raw = bytes(idb)
         if world > 1:
-            if rendezvous is None:
-                raise ValueError("more than one rank needs a rendezvous callable to pass the id")
             raw = rendezvous(raw)
+        if why is not None:
+            raise why
+        if not any(raw):
+            raise RuntimeError("rank 0 could not make a communicator id")
         idb = (C.c_ubyte * 128).from_buffer_copy(raw)
         self.rank, self.world = rank, world
         self.handle = capi.check_handle(L.wp_comm_create(idb, world, rank), "wp_comm_create")
@@ -241,19 +250,20 @@ def gloo_rendezvous(dist, src=0):
     return bcast
 
 
-def reduce_master_bus(bus, dist, dst=0, comm=None):
+def reduce_master_bus(bus, dist, dst=0, comm=None, group=None):
     """The path's one exchange step: sum the rank-local partial buses onto rank
     `dst`.  With `comm` (a Comm) the reduce is wp_bus_reduce, RCCL called through the C ABI;
     otherwise torch.distributed carries it (gloo for CPU tensors in the CPU rehearsal of the
-    multi-rank flow).  `bus` is a single tensor [channels, frames]; one message per call."""
+    multi-rank flow; `group` selects a process group other than the default one).  `bus` is a
+    single tensor [channels, frames]; one message per call."""
     if comm is not None:
         comm.reduce(bus, dst=dst)
         return bus
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        if bus.is_cuda and dist.get_backend() == "gloo":  # rehearsal without RCCL: stage through the host
+        if bus.is_cuda and dist.get_backend(group) == "gloo":  # rehearsal without RCCL: stage through the host
             host = bus.cpu()
-            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
             bus.copy_(host)
         else:
-            dist.reduce(bus, dst=dst, op=dist.ReduceOp.SUM)
+            dist.reduce(bus, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return bus
