@@ -60,6 +60,8 @@ def parse():
                     "for rehearsing the multi-rank flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
+                    help="wp_tune(knob, value) before the plans are made (measurements of the library's alternatives)")
     ap.add_argument("--cpu-tracks", type=int, default=20, help="stereo tracks in the bounded CPU sample")
     return ap.parse_args()
 
@@ -302,6 +304,9 @@ def main():
         fence()
         return max_over_ranks(time.perf_counter() - t0)
 
+    for kv in a.tune:
+        knob, value = kv.split("=")
+        capi.check(capi.lib().wp_tune(int(knob), int(value)), "wp_tune")
     w = Workload(a, a.config, rank, world, torch, dev)
     F, M, tracks, njobs, out_len = w.F, w.M, w.tracks, w.njobs, w.out_len
     conv, x, vol = w.conv, w.x, w.vol
@@ -398,9 +403,9 @@ def main():
     B = int(capi.lib().wp_conv_info(conv.handle, 2))
     T = int(capi.lib().wp_conv_info(conv.handle, 1))
     P = int(capi.lib().wp_conv_info(conv.handle, 3))
-    N2 = int(capi.lib().wp_conv_info(conv.handle, 7)) if lf else 0
-    nfr = int(capi.lib().wp_conv_info(conv.handle, 8)) if lf else 0
-    hop = int(capi.lib().wp_conv_info(conv.handle, 9)) if lf else 1
+    # long-frame form: runs of equal frames (frame length N2 samples = N2/2 complex points, frames, advance, first sample)
+    nruns = int(capi.lib().wp_conv_info(conv.handle, 10)) if lf else 0
+    runs = [tuple(int(capi.lib().wp_conv_info(conv.handle, 16 + 4 * i + k)) for k in range(4)) for i in range(nruns)]
 
     # secondary measurement for multi-GPU runs: the 2048-track render's per-GPU share (4 s IR per job)
     c5_extra = None
@@ -438,14 +443,16 @@ def main():
         Tin = min(Tout, (F + B - 1) // B + 1)
         # algorithmic bytes per launch: every operand of the kernel read or written exactly once
         # long-frame form: frames of N2 samples = Nc complex points, advancing by hop
-        nfr_run = (F + hop - 1) // hop if fused else nfr
+        # (with several runs of frames a kernel is launched once per run: bytes and times are per step, summed over the runs)
+        pts_all = sum(n2 // 2 * nf for n2, nf, hop, base in runs)
+        pts_run = sum(n2 // 2 * min(nf, max(0, -(-(F - base) // hop))) for n2, nf, hop, base in runs) if fused else pts_all
         alg = {
-            "k_lf_fwd": njobs * (4 * F + 8 * (N2 // 2) * nfr_run),
+            "k_lf_fwd": njobs * (4 * F + 8 * pts_run),
             # (+ 8 bytes per frame point when every job has a kernel spectrum of its own to read)
-            "k_lf_mid": njobs * (16 + (8 if a.config == "c5" else 0)) * (N2 // 2) * nfr_run,
-            "k_lf_inv": njobs * (8 * (N2 // 2) * nfr + 4 * out_len),
-            "k_lf_inv_mix": njobs * 8 * (N2 // 2) * nfr_run + 2 * 2 * 4 * F,
-            "k_lf_inv_mix_w": njobs * (8 * (N2 // 2) * nfr + 4 * out_len) + 2 * 2 * 4 * F,
+            "k_lf_mid": njobs * (16 + (8 if a.config == "c5" else 0)) * pts_run,
+            "k_lf_inv": njobs * (8 * pts_all + 4 * out_len),
+            "k_lf_inv_mix": njobs * 8 * pts_run + 2 * 2 * 4 * F,
+            "k_lf_inv_mix_w": njobs * (8 * pts_all + 4 * out_len) + 2 * 2 * 4 * F,
             "k_fft_fwd": njobs * (4 * F + 8 * B * Tin),
             "k_mac": njobs * (8 * B * Tin + 8 * B * Tout),
             "k_fft_inv": njobs * (8 * B * T + 4 * out_len),
@@ -474,7 +481,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "batched reverb+mix: %d stereo tracks/GPU x %.0f s @ %d Hz x %s, "
                                    "one go() per channel-job then mixBuffers into a stereo bus" % (tracks, a.seconds, a.rate, ir_desc),
-                       "name": a.config, "tracks_per_gpu": tracks, "frames": F, "ir_len": M, "form": ("long-frame overlap-save: %d frames of %d samples per job, hop %d" % (nfr, N2, hop)) if lf
+                       "name": a.config, "tracks_per_gpu": tracks, "frames": F, "ir_len": M, "form": ("long-frame overlap-save, per job: " + " + ".join("%d frame(s) of %d samples advancing by %d" % (nf, n2, hop) for n2, nf, hop, base in runs)) if lf
                        else ("partitioned overlap-save: %d partitions of %d, %d blocks per job" % (P, B, T)),
                        "partition": B, "partitions": P, "blocks": T,
                        "path": {"fused": "wp_conv_mix_run_dev (bus only)", "onepass": "wp_conv_run_mix_dev (all go() results + bus in one pass)",
@@ -483,7 +490,7 @@ def main():
             "verified": verified,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": avg,
+                         "launches_per_step": max(1, nruns), "kernel_ms": avg,
                          "kernel_GBs": {k: alg[k] / (avg[k] * 1e-3) / 1e9 for k in avg if avg[k] > 0},
                          "pipeline_compulsory_GBs": (njobs * 4 * F + (16 * F if fused else njobs * 4 * out_len)) / (dt / K) / 1e9},
         }

@@ -304,15 +304,27 @@ static int get_lf_tables(int dev, int R, const c32 **out)
 }
 
 // Long-frame form (wp_longframe_kernels.hip) for results much longer than the impulse response:
-// frames of N2 = 2*R*LF_C samples advancing by hop = N2 - mpad.  Picks the frame size that moves
-// the fewest bytes (20 per frame sample + 4 per output sample, + 8 per frame point when every job
-// has a kernel spectrum of its own) and returns 0 unless that is below the partitioned form's 40
-// bytes per output sample.
-struct LfGeom {
-    int R = 0;  // 0: partitioned form
+// frames of N2 = 2*R*LF_C samples advancing by hop = N2 - mpad.  A result is covered by up to
+// LF_MAX_SEG runs of equal frames, largest first (e.g. three frames of 2^20 samples and one of
+// 2^18 for a 60 s track with a 2 s impulse response: 3.41 M frame samples where seven frames of
+// 2^19 take 3.67 M).  Picks the cover that moves the fewest bytes (20 per frame sample + 4 per
+// output sample, + 8 per frame point when every job has a kernel spectrum of its own; every
+// further run of frames must pay for its three extra launches with 3 % of the bytes) and returns
+// none unless that is below the partitioned form's 40 bytes per output sample.
+struct LfSeg {
+    int R = 0;
     int nframes = 0;
-    int64_t hop = 0, mpad = 0;
+    int64_t hop = 0;
+    int64_t base = 0;  // first output sample of the run
+    int64_t pts = 0;   // complex points of the run per job: nframes * R * LF_C
 };
+struct LfGeom {
+    int nseg = 0;  // 0: partitioned form
+    LfSeg seg[LF_MAX_SEG];
+    int64_t mpad = 0;
+    int64_t pts = 0;  // complex points per job over all runs
+};
+static int g_tune_lf_runs = 0;  // WP_TUNE_LF_RUNS: 0 = up to LF_MAX_SEG runs of frames, n = at most n
 static LfGeom choose_lf(int64_t L, int64_t M, int nch)
 {
     LfGeom best;
@@ -320,21 +332,77 @@ static LfGeom choose_lf(int64_t L, int64_t M, int nch)
     const int64_t out_len = L + M;
     double best_cost = 0.95 * 40.0 * (double)out_len;  // measured: at 0.92 of the partitioned form's bytes the long-frame form took 0.81 of its time
     if (g_tune_form == 2) best_cost = 1e300;
-    for (int R : {128, 256}) {
-        const int64_t N2 = 2 * (int64_t)R * LF_C;
-        const int64_t mpad = ((M - 1 + 63) / 64) * 64;
-        if (mpad > N2 / 2) continue;
-        const int64_t hop = N2 - mpad;
-        const int64_t nf = (out_len + hop - 1) / hop;
-        if (nf > 65535) continue;
-        double cost = (double)nf * (double)N2 * 20.0 + 4.0 * (double)out_len;
-        if (nch > 4) cost += (double)nf * (double)(N2 / 2) * 8.0;
-        if (cost < best_cost) {
-            best_cost = cost;
-            best.R = R;
-            best.nframes = (int)nf;
-            best.hop = hop;
-            best.mpad = mpad;
+    const int64_t mpad = ((M - 1 + 63) / 64) * 64;
+    const int Rs[3] = {256, 128, 64};
+    int64_t N2[3], hop[3];
+    bool okR[3];
+    for (int i = 0; i < 3; i++) {
+        N2[i] = 2 * (int64_t)Rs[i] * LF_C;
+        okR[i] = mpad <= N2[i] / 2;
+        hop[i] = N2[i] - mpad;
+    }
+    const int max_runs = g_tune_lf_runs > 0 && g_tune_lf_runs < LF_MAX_SEG ? g_tune_lf_runs : LF_MAX_SEG;
+    auto consider = [&](const int64_t n[3]) {
+        int64_t covered = 0, samples = 0;
+        int runs = 0;
+        for (int i = 0; i < 3; i++) {
+            if (n[i] < 0 || n[i] > 65535 || (n[i] > 0 && !okR[i])) return;
+            covered += n[i] * hop[i];
+            samples += n[i] * N2[i];
+            runs += n[i] > 0;
+        }
+        if (covered < out_len || runs == 0 || runs > max_runs) return;
+        double cost = (double)samples * 20.0 + 4.0 * (double)out_len;
+        if (nch > 4) cost += (double)(samples / 2) * 8.0;
+        cost *= 1.0 + 0.03 * (runs - 1);
+        if (cost >= best_cost) return;
+        best_cost = cost;
+        best = LfGeom();
+        best.mpad = mpad;
+        int64_t base = 0;
+        for (int i = 0; i < 3; i++) {
+            if (!n[i]) continue;
+            LfSeg &g = best.seg[best.nseg++];
+            g.R = Rs[i];
+            g.nframes = (int)n[i];
+            g.hop = hop[i];
+            g.base = base;
+            g.pts = n[i] * (int64_t)Rs[i] * LF_C;
+            base += n[i] * hop[i];
+            best.pts += g.pts;
+        }
+    };
+    auto ceil_div = [](int64_t a, int64_t b) { return a <= 0 ? (int64_t)0 : (a + b - 1) / b; };
+    // n0 frames of the largest size, the rest of the result by at most 8 + 8 smaller frames
+    for (int p = 0; p < 3; p++) {
+        if (!okR[p]) continue;
+        const int64_t hi = ceil_div(out_len, hop[p]);
+        for (int64_t np = hi; np >= 0 && np >= hi - 4; np--) {
+            int64_t n[3] = {0, 0, 0};
+            n[p] = np;
+            const int64_t rem = out_len - np * hop[p];
+            if (rem <= 0 || p == 2) {
+                consider(n);
+                continue;
+            }
+            for (int q = p + 1; q < 3; q++) {
+                if (!okR[q]) continue;
+                const int64_t hq = ceil_div(rem, hop[q]);
+                for (int64_t nq = hq; nq >= 0 && nq >= hq - 8; nq--) {
+                    if (nq > 8) break;
+                    n[q] = nq;
+                    const int64_t rem2 = rem - nq * hop[q];
+                    if (q + 1 < 3) n[q + 1] = 0;
+                    if (rem2 <= 0) {
+                        consider(n);
+                    } else if (q + 1 < 3 && okR[q + 1] && ceil_div(rem2, hop[q + 1]) <= 8) {
+                        n[q + 1] = ceil_div(rem2, hop[q + 1]);
+                        consider(n);
+                        n[q + 1] = 0;
+                    }
+                }
+                n[q] = 0;
+            }
         }
     }
     return best;
@@ -370,9 +438,9 @@ struct wp_ir {
     bool shared;       // Hp belongs to g_ir_cache[key]
     IrKey key;
     const c32 *tables;
-    LfGeom lf;             // long-frame geometry for results of L+M samples (lf.R == 0: not used)
-    c32 *lf_Hs;            // [nch][R][LF_C] real spectra of the zero-padded kernels, scaled; owned by this handle
-    const c32 *lf_tab;     // long-frame tables of lf.R
+    LfGeom lf;             // long-frame geometry for results of L+M samples (lf.nseg == 0: not used)
+    c32 *lf_Hs[LF_MAX_SEG];       // per run of frames: [nch][R][LF_C] real spectra of the zero-padded kernels, scaled; owned by this handle
+    const c32 *lf_tab[LF_MAX_SEG];  // long-frame tables of each run's R
     const c32 *lf_tab_row; // tables of the 2048-point row transforms
     int64_t bytes;
     wp_conv *single;   // lazily built 1-job plan for wp_convolve / wp_convolve_dev
@@ -394,8 +462,10 @@ struct wp_conv {
     int32_t *job_irch;  // device table of each job's IR channel; nullptr for one-job plans, whose
     int irch_all;       // channel travels as a launch argument (it changes from call to call)
     c32 *Z, *W;
-    bool lf;            // long-frame form: A holds [njobs][ir->lf.nframes][R][LF_C] instead of Z and W
+    bool lf;            // long-frame form: A holds, run of frames after run, [njobs][nframes][R][LF_C] instead of Z and W
     c32 *A;
+    hipStream_t side;   // plans with more than one run of frames: the shorter runs' inverse passes go here,
+    hipEvent_t fork, join;  // beside the first run's on the caller's stream
     // one stream at a time may use a plan (Z and W are shared by its calls): a call on a
     // different stream than the previous one first waits for that call's last kernel
     hipStream_t last_stream;
@@ -446,6 +516,10 @@ extern "C" int wp_tune(int what, int64_t value)
     case WP_TUNE_CONV_FORM:
         if (value < 0 || value > 2) break;
         g_tune_form = (int)value;
+        return WP_OK;
+    case WP_TUNE_LF_RUNS:
+        if (value < 0 || value > LF_MAX_SEG) break;
+        g_tune_lf_runs = (int)value;
         return WP_OK;
     case WP_TUNE_FWD_FORM:
         if (value < 0 || value > 2) break;
@@ -505,14 +579,23 @@ static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, 
     ir->Hp = nullptr;
     ir->shared = false;
     ir->lf = choose_lf(L, M, nch);
-    ir->lf_Hs = nullptr;
-    ir->lf_tab = ir->lf_tab_row = nullptr;
+    for (int i = 0; i < LF_MAX_SEG; i++) {
+        ir->lf_Hs[i] = nullptr;
+        ir->lf_tab[i] = nullptr;
+    }
+    ir->lf_tab_row = nullptr;
+    auto free_lf = [&]() {
+        for (auto &h : ir->lf_Hs) {
+            if (h) (void)hipFree(h);
+            h = nullptr;
+        }
+    };
     c32 *Zir = nullptr;
     auto bail = [&](const char *what, hipError_t e) {
         fail(WP_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
         if (Zir) (void)hipFree(Zir);
         if (ir->Hp) (void)hipFree(ir->Hp);
-        if (ir->lf_Hs) (void)hipFree(ir->lf_Hs);
+        free_lf();
         delete ir;
         return (wp_ir *)nullptr;
     };
@@ -522,24 +605,26 @@ static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, 
     }
     const size_t hbytes = sizeof(c32) * (size_t)nch * ir->Pp * ir->B;
     ir->bytes = (int64_t)hbytes;
-    if (ir->lf.R) {
+    for (int i = 0; i < ir->lf.nseg; i++) {
         // kernel spectra of the long-frame form: the kernels as one "frame" each, through the same
-        // column and row passes the signal takes
-        const size_t lbytes = sizeof(c32) * (size_t)nch * ir->lf.R * LF_C;
+        // column and row passes the signal takes, once per frame size
+        const int R = ir->lf.seg[i].R;
+        const size_t lbytes = sizeof(c32) * (size_t)nch * R * LF_C;
         c32 *tmpA = nullptr;
         hipError_t e = hipSuccess;
-        if (get_lf_tables(dev, ir->lf.R, &ir->lf_tab) != WP_OK || get_tables(dev, LF_C, &ir->lf_tab_row) != WP_OK) {
+        if (get_lf_tables(dev, R, &ir->lf_tab[i]) != WP_OK || get_tables(dev, LF_C, &ir->lf_tab_row) != WP_OK) {
+            free_lf();
             delete ir;
             return nullptr;
         }
-        if ((e = hipMalloc((void **)&ir->lf_Hs, lbytes)) == hipSuccess) e = hipMalloc((void **)&tmpA, lbytes);
-        if (e == hipSuccess) e = launch_lf_fwd(ir->lf.R, ir_dev, ch_stride, M, tmpA, 1, 1, nch, 0, 0, ir->lf_tab, s);
-        if (e == hipSuccess) e = launch_lf_mid(true, ir->lf.R, tmpA, ir->lf_Hs, nullptr, 0, 1, 1, nch, ir->lf_tab, ir->lf_tab_row, s);
+        if ((e = hipMalloc((void **)&ir->lf_Hs[i], lbytes)) == hipSuccess) e = hipMalloc((void **)&tmpA, lbytes);
+        if (e == hipSuccess) e = launch_lf_fwd(R, ir_dev, ch_stride, M, tmpA, 1, 1, nch, 0, 0, 0, ir->lf_tab[i], s);
+        if (e == hipSuccess) e = launch_lf_mid(true, R, tmpA, ir->lf_Hs[i], nullptr, 0, 1, 1, nch, ir->lf_tab[i], ir->lf_tab_row, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (tmpA) (void)hipFree(tmpA);
         if (e != hipSuccess) {
             fail(WP_ERR_HIP, "long-frame kernel spectra: %s", hipGetErrorString(e));
-            if (ir->lf_Hs) (void)hipFree(ir->lf_Hs);
+            free_lf();
             delete ir;
             return nullptr;
         }
@@ -653,7 +738,8 @@ extern "C" void wp_ir_destroy(wp_ir *ir)
     if (ir->wrap_lin) (void)hipFree(ir->wrap_lin);
     if (ir->stage_in) (void)hipFree(ir->stage_in);
     if (ir->stage_out) (void)hipFree(ir->stage_out);
-    if (ir->lf_Hs) (void)hipFree(ir->lf_Hs);
+    for (auto &h : ir->lf_Hs)
+        if (h) (void)hipFree(h);
     if (ir->shared) {
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = g_ir_cache.find(ir->key);
@@ -679,7 +765,9 @@ extern "C" int64_t wp_ir_info(const wp_ir *ir, int which)
     case 5: return ir->L + ir->M;
     case 6: return wp_next_pot((int32_t)(ir->L + ir->M));
     case 7: return ir->bytes;
-    case 9: return ir->lf.R ? 2 * (int64_t)ir->lf.R * LF_C : 0;
+    case 9: return ir->lf.nseg ? 2 * (int64_t)ir->lf.seg[0].R * LF_C : 0;
+    case 10: return ir->lf.nseg;
+    case 11: return 2 * ir->lf.pts;
     case 8: {
         if (!ir->shared) return 1;
         std::lock_guard<std::mutex> lk(g_mu);
@@ -730,6 +818,8 @@ static void plan_geometry(wp_conv *c, wp_ir *ir, int njobs, int64_t out_len)
     c->Z = c->W = nullptr;
     c->lf = false;
     c->A = nullptr;
+    c->side = nullptr;
+    c->fork = c->join = nullptr;
     c->bytes = 0;
     c->prof = c->prof_valid = false;
     for (auto &e : c->ev) e = nullptr;
@@ -761,10 +851,15 @@ static wp_conv *conv_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t
         e = hipMalloc((void **)&c->job_irch, sizeof(int32_t) * njobs);
         if (e == hipSuccess) e = hipMemcpy(c->job_irch, job_ch, sizeof(int32_t) * njobs, hipMemcpyHostToDevice);
     }
-    c->lf = allow_lf && ir->lf.R && out_len == ir->L + ir->M;
-    const size_t abytes = c->lf ? sizeof(c32) * (size_t)njobs * ir->lf.nframes * ir->lf.R * LF_C : 0;
+    c->lf = allow_lf && ir->lf.nseg && out_len == ir->L + ir->M;
+    const size_t abytes = c->lf ? sizeof(c32) * (size_t)njobs * ir->lf.pts : 0;
     if (c->lf) {
         if (e == hipSuccess) e = hipMalloc((void **)&c->A, abytes);
+        if (ir->lf.nseg > 1) {
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join, hipEventDisableTiming);
+        }
     } else {
         if (e == hipSuccess) e = hipMalloc((void **)&c->Z, sbytes);
         if (e == hipSuccess) e = hipMalloc((void **)&c->W, sbytes);
@@ -788,6 +883,12 @@ extern "C" void wp_conv_destroy(wp_conv *c)
     if (c->A) (void)hipFree(c->A);
     if (c->vol_dev) (void)hipFree(c->vol_dev);
     if (c->done) (void)hipEventDestroy(c->done);
+    if (c->fork) (void)hipEventDestroy(c->fork);
+    if (c->join) (void)hipEventDestroy(c->join);
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(c->side);
+    }
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     delete c;
@@ -823,9 +924,22 @@ extern "C" int64_t wp_conv_info(const wp_conv *c, int which)
     case 4: return c->tchunk;
     case 5: return c->gather ? 1 : 0;
     case 6: return c->lf ? 1 : 0;
-    case 7: return c->lf ? 2 * (int64_t)c->ir->lf.R * LF_C : 0;
-    case 8: return c->lf ? c->ir->lf.nframes : 0;
-    case 9: return c->lf ? c->ir->lf.hop : 0;
+    case 7: return c->lf ? 2 * (int64_t)c->ir->lf.seg[0].R * LF_C : 0;
+    case 8: return c->lf ? c->ir->lf.seg[0].nframes : 0;
+    case 9: return c->lf ? c->ir->lf.seg[0].hop : 0;
+    case 10: return c->lf ? c->ir->lf.nseg : 0;
+    case 11: return c->lf ? 2 * c->ir->lf.pts : 0;
+    }
+    if (which >= 16 && which < 16 + 4 * LF_MAX_SEG) {  // run of frames (which-16)/4: frame length, frames, hop, first output sample
+        const int i = (which - 16) / 4;
+        if (!c->lf || i >= c->ir->lf.nseg) return 0;
+        const LfSeg &g = c->ir->lf.seg[i];
+        switch ((which - 16) % 4) {
+        case 0: return 2 * (int64_t)g.R * LF_C;
+        case 1: return g.nframes;
+        case 2: return g.hop;
+        case 3: return g.base;
+        }
     }
     return WP_ERR_INVALID;
 }
@@ -870,16 +984,65 @@ static int check_in_len(const wp_ir *ir, int64_t in_len, bool wrap_ok = false)
 
 // forward FFTs + spectral MAC for output blocks [0, Tout); leaves W ready
 // long-frame form: column pass + row pass for the first frames_run frames; leaves A ready for launch_lf_inv
-static int conv_front_lf(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len, int frames_run, hipStream_t s)
+// `limit`: samples of the result that are needed (frames beyond them are skipped)
+static int lf_frames_run(const LfSeg &g, int64_t limit)
+{
+    if (limit <= g.base) return 0;
+    const int64_t n = (limit - g.base + g.hop - 1) / g.hop;
+    return n < g.nframes ? (int)n : g.nframes;
+}
+static c32 *lf_seg_A(const wp_conv *c, int i)
+{
+    int64_t off = 0;
+    for (int k = 0; k < i; k++) off += c->ir->lf.seg[k].pts;
+    return c->A + (int64_t)c->njobs * off;
+}
+static int conv_front_lf(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len, int64_t limit, hipStream_t s)
 {
     const wp_ir *ir = c->ir;
     if (c->prof) HIPCHK(hipEventRecord(c->ev[0], s));
-    HIPCHK(launch_lf_fwd(ir->lf.R, in_dev, in_stride, in_len, c->A, ir->lf.nframes, frames_run, c->njobs, ir->lf.hop, ir->lf.mpad,
-                         ir->lf_tab, s));
+    for (int i = 0; i < ir->lf.nseg; i++) {
+        const LfSeg &g = ir->lf.seg[i];
+        HIPCHK(launch_lf_fwd(g.R, in_dev, in_stride, in_len, lf_seg_A(c, i), g.nframes, lf_frames_run(g, limit), c->njobs, g.base,
+                             g.hop, ir->lf.mpad, ir->lf_tab[i], s));
+    }
     if (c->prof) HIPCHK(hipEventRecord(c->ev[1], s));
-    HIPCHK(launch_lf_mid(false, ir->lf.R, c->A, ir->lf_Hs, c->job_irch, c->irch_all, ir->lf.nframes, frames_run, c->njobs,
-                         ir->lf_tab, ir->lf_tab_row, s));
+    for (int i = 0; i < ir->lf.nseg; i++) {
+        const LfSeg &g = ir->lf.seg[i];
+        HIPCHK(launch_lf_mid(false, g.R, lf_seg_A(c, i), ir->lf_Hs[i], c->job_irch, c->irch_all, g.nframes, lf_frames_run(g, limit),
+                             c->njobs, ir->lf_tab[i], ir->lf_tab_row, s));
+    }
     if (c->prof) HIPCHK(hipEventRecord(c->ev[2], s));
+    return WP_OK;
+}
+// Inverse passes of every run of frames.  The runs write disjoint sample ranges; the shorter runs (few
+// workgroups, each a serial chain over the sources when the bus is folded) go to the plan's side
+// stream so that they overlap the first run's pass.
+static int conv_back_lf(wp_conv *c, int64_t limit, int nsrc, float *bus0, float *bus1, int64_t tl, const double *vol,
+                        float *out_dev, int64_t out_stride, int64_t out_len, hipStream_t s)
+{
+    const wp_ir *ir = c->ir;
+    bool forked = false;
+    for (int i = ir->lf.nseg - 1; i >= 0; i--) {
+        const LfSeg &g = ir->lf.seg[i];
+        const int fr = lf_frames_run(g, limit);
+        if (fr <= 0) continue;
+        hipStream_t q = s;
+        if (i > 0 && c->side) {
+            if (!forked) {
+                HIPCHK(hipEventRecord(c->fork, s));
+                HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
+                forked = true;
+            }
+            q = c->side;
+        }
+        HIPCHK(launch_lf_inv(g.R, lf_seg_A(c, i), g.nframes, fr, c->njobs, g.base, g.hop, ir->lf.mpad, nsrc, bus0, bus1, tl, vol,
+                             out_dev, out_stride, out_len, ir->lf_tab[i], q));
+    }
+    if (forked) {
+        HIPCHK(hipEventRecord(c->join, c->side));
+        HIPCHK(hipStreamWaitEvent(s, c->join, 0));
+    }
     return WP_OK;
 }
 
@@ -917,9 +1080,8 @@ extern "C" int wp_conv_run_dev(wp_conv *c, const float *in_dev, int64_t in_strid
     if (int rc = plan_enter(c, s)) return rc;
     if (prev_dev && prev_len > c->out_len) prev_len = c->out_len;
     if (c->lf) {
-        if (int rc = conv_front_lf(c, in_dev, in_stride, in_len, ir->lf.nframes, s)) return rc;
-        HIPCHK(launch_lf_inv(ir->lf.R, c->A, ir->lf.nframes, ir->lf.nframes, c->njobs, ir->lf.hop, ir->lf.mpad, 0, nullptr, nullptr, 0,
-                             nullptr, out_dev, out_stride, c->out_len, ir->lf_tab, s));
+        if (int rc = conv_front_lf(c, in_dev, in_stride, in_len, c->out_len, s)) return rc;
+        if (int rc = conv_back_lf(c, c->out_len, 0, nullptr, nullptr, 0, nullptr, out_dev, out_stride, c->out_len, s)) return rc;
         if (prev_dev && prev_len > 0) HIPCHK(launch_add_prev(out_dev, out_stride, prev_dev, prev_stride, prev_len, c->njobs, s));
     } else {
         if (int rc = conv_front(c, in_dev, in_stride, in_len, c->T, s)) return rc;
@@ -956,10 +1118,10 @@ static int conv_mix_common(wp_conv *c, const float *in_dev, int64_t in_stride, i
     }
     if (c->lf) {
         // with per-job results every frame is needed; otherwise only those that reach the bus
-        const int frames_run = out_dev ? ir->lf.nframes : (int)((tl + ir->lf.hop - 1) / ir->lf.hop);
-        if (int rc = conv_front_lf(c, in_dev, in_stride, in_len, frames_run, s)) return rc;
-        HIPCHK(launch_lf_inv(ir->lf.R, c->A, ir->lf.nframes, frames_run, c->njobs, ir->lf.hop, ir->lf.mpad, nsrc, tgt_dev[0],
-                             tgt_dev[1], tl, c->vol_dev, out_dev, out_stride, ir->L + ir->M, ir->lf_tab, s));
+        const int64_t limit = out_dev ? ir->L + ir->M : tl;
+        if (int rc = conv_front_lf(c, in_dev, in_stride, in_len, limit, s)) return rc;
+        if (int rc = conv_back_lf(c, limit, nsrc, tgt_dev[0], tgt_dev[1], tl, c->vol_dev, out_dev, out_stride, ir->L + ir->M, s))
+            return rc;
     } else {
         // with per-job results every output block is needed; otherwise only those that reach the bus
         const int Tout = out_dev ? c->T : (int)((tl + ir->B - 1) / ir->B);

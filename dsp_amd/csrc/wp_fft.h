@@ -137,8 +137,13 @@ struct Dft<4, INV> {
 // runs PT/R butterflies per thread.
 template <int B>
 struct FftPlan;
-// 128 and 256 points: the strided (column) transforms of the long-frame convolution; 8 or 16
-// threads of 16 points per transform, one exchange
+// 64, 128 and 256 points: the strided (column) transforms of the long-frame convolution; 4, 8 or
+// 16 threads of 16 points per transform, one exchange
+template <>
+struct FftPlan<64> {
+    static constexpr int PT = 16, NSTAGE = 2;
+    static constexpr int radix(int s) { return s == 0 ? 16 : 4; }
+};
 template <>
 struct FftPlan<128> {
     static constexpr int PT = 16, NSTAGE = 2;
@@ -230,28 +235,50 @@ WP_HD void stage_load(int tid, c32 *v, Src &&src)
         static_for<0, R>([&](auto t) { v[u * R + t] = src(j + t * (B / R)); });
     });
 }
-// compute: twiddle + DFT_R, in registers
+// compute: twiddle + DFT_R, in registers.  One table lookup per butterfly, then
+// W^(t*k) = W^(a*k) * W^(b*k) with a = t/2, b = t - a: every power is at most log2(t) complex
+// products away from a correctly rounded value.  Against a lookup per power this trades R-2
+// table reads (two each in the two-level stages) for R-2 complex products on an under-used
+// VALU: fewer registers, slightly faster kernels, errors still three orders below the 1e-5 bar.
+// stage_first_powers + stage_compute_with are the two halves of stage_compute, for kernels that
+// run the same stage many times (the looked-up powers depend on the thread only, and a lookup
+// inside such a loop makes every pass wait for all the loads in flight before it).
 template <int B, int S, bool INV>
-WP_HD void stage_compute(int tid, c32 *v, const TwTables<B> &tw)
+WP_HD void stage_first_powers(int tid, c32 *w1, const TwTables<B> &tw)
 {
     constexpr int PT = FftPlan<B>::PT, R = FftPlan<B>::radix(S), NT = B / PT, NB = PT / R;
     constexpr int NS = plan_ns<B>(S);
     static_for<0, NB>([&](auto u) {
         if constexpr (NS > 1) {
             const int j = tid + u * NT;
-            const int k = j & (NS - 1);
-            // One table lookup, then W^(t*k) = W^(a*k) * W^(b*k) with a = t/2, b = t - a: every
-            // power is at most log2(t) complex products away from a correctly rounded value.
-            // Against a lookup per power this trades R-2 LDS reads (two each in the two-level
-            // stages) for R-2 complex products on an under-used VALU: fewer registers, slightly
-            // faster kernels, errors still three orders below the 1e-5 bar.
+            w1[u] = stage_twiddle<B, NS * R, INV>(tw, j & (NS - 1));
+        } else {
+            w1[u] = c32{1.0f, 0.0f};
+        }
+    });
+}
+template <int B, int S, bool INV>
+WP_HD void stage_compute_with(c32 *v, const c32 *w1)
+{
+    constexpr int PT = FftPlan<B>::PT, R = FftPlan<B>::radix(S), NB = PT / R;
+    constexpr int NS = plan_ns<B>(S);
+    static_for<0, NB>([&](auto u) {
+        if constexpr (NS > 1) {
             c32 w[R];
-            w[1] = stage_twiddle<B, NS * R, INV>(tw, k);
+            w[1] = w1[u];
             static_for<2, R>([&](auto t) { w[t] = cmul(w[int(t) / 2], w[int(t) - int(t) / 2]); });
             static_for<1, R>([&](auto t) { v[u * R + t] = cmul(v[u * R + t], w[t]); });
         }
         Dft<R, INV>::run(v + u * R);
     });
+}
+template <int B, int S, bool INV>
+WP_HD void stage_compute(int tid, c32 *v, const TwTables<B> &tw)
+{
+    constexpr int NB = FftPlan<B>::PT / FftPlan<B>::radix(S);
+    c32 w1[NB];
+    stage_first_powers<B, S, INV>(tid, w1, tw);
+    stage_compute_with<B, S, INV>(v, w1);
 }
 // store: dst((j-k)*R + k + t*NS, X[t], t, u)  (t, u are compile-time constants)
 template <int B, int S, bool INV, class Dst>

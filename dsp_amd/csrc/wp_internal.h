@@ -48,7 +48,9 @@ hipError_t launch_big_fft(const float *src, int64_t n_real, int64_t N, int inver
                           int64_t n_out, hipStream_t s);
 
 // ---- long-frame convolution (wp_longframe_kernels.hip) ----
-// A frame of 2*Nc real samples = Nc = R*LF_C complex points; R = 128 or 256.
+// A frame of 2*Nc real samples = Nc = R*LF_C complex points; R = 64, 128 or 256.  A job's result is covered by
+// up to LF_MAX_SEG runs of equal frames (largest first); `base` is the first output sample of a run.
+constexpr int LF_MAX_SEG = 3;
 constexpr int LF_C = 2048;
 // device table block of one R (c32 entries):
 //   [LF_T256, +256)  exp(-2*pi*i*a/256)            [LF_ROW, +256)   exp(-i*pi*r/R), r < R
@@ -59,13 +61,13 @@ constexpr int LF_T256 = 0, LF_ROW = 256, LF_COL = 512, LF_FLO = 2560, LF_FHI = 3
               LF_TABLE_POINTS = 6400;
 // nframes: frames per job in A (the stride); frames_run <= nframes: how many of them this launch handles
 hipError_t launch_lf_fwd(int R, const float *in, int64_t in_stride, int64_t in_len, c32 *A, int nframes, int frames_run,
-                         int njobs, int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s);
+                         int njobs, int64_t base, int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s);
 // tab_row: the table block of the 2048-point plan (row transforms)
 hipError_t launch_lf_mid(bool hprep, int R, c32 *A, c32 *Hs, const int32_t *job_irch, int irch_all, int nframes,
                          int frames_run, int njobs, const c32 *tab, const c32 *tab_row, hipStream_t s);
 // bus0 == nullptr: plain results for every job; otherwise the bus fold over nsrc stereo sources (jobs 2s, 2s+1),
 // with the per-job results too when out != nullptr
-hipError_t launch_lf_inv(int R, const c32 *A, int nframes, int frames_run, int njobs, int64_t hop, int64_t mpad, int nsrc,
+hipError_t launch_lf_inv(int R, const c32 *A, int nframes, int frames_run, int njobs, int64_t base, int64_t hop, int64_t mpad, int nsrc,
                          float *bus0, float *bus1, int64_t tl, const double *vol, float *out, int64_t out_stride,
                          int64_t out_len, const c32 *tab, hipStream_t s);
 // out[job][i] += prev[job][i], i < prev_len (the carried reverb tail, lib/impulse-reverb.js:14-16)

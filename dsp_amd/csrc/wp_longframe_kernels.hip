@@ -62,8 +62,8 @@ __device__ __forceinline__ TwTables<R> lf_col_tables(const c32 *__restrict__ tab
 // starting at sample 0.
 template <int R>
 __global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_fwd(const float *__restrict__ in, int64_t in_stride, int64_t in_len,
-                                                            c32 *__restrict__ A, int nframes, int64_t hop, int64_t mpad,
-                                                            const c32 *__restrict__ tab)
+                                                            c32 *__restrict__ A, int nframes, int64_t base, int64_t hop,
+                                                            int64_t mpad, const c32 *__restrict__ tab)
 {
     constexpr int C = LF_C, NTF = R / 16, PT = 16;
     constexpr int64_t Nc = (int64_t)R * C;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_fwd(const float *__restr
     const int frame = blockIdx.y, job = blockIdx.z;
     const TwTables<R> tw = lf_col_tables<R>(tab);
     const float *x = in + (int64_t)job * in_stride;
-    const int64_t start = (int64_t)frame * hop - mpad;  // sample at frame position 0
+    const int64_t start = base + (int64_t)frame * hop - mpad;  // sample at frame position 0 (base: first output sample of this run of frames)
     const bool fast = start >= 0 && start + 2 * Nc <= in_len && ((reinterpret_cast<uintptr_t>(x + start) & 7) == 0);
 
     c32 v[PT];
@@ -174,9 +174,11 @@ __global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__rest
 // Inverse column pass + output (+ master-bus fold).  MIX: workgroup = (tile, frame) of ONE bus
 // channel (blockIdx.z), walking the stereo sources in order (jobs 2s + channel) with the next
 // source's tile prefetched; otherwise blockIdx.z is the job.  WRITE: store the job's samples.
-template <int R, bool MIX, bool WRITE>
-__global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_inv(const c32 *__restrict__ A, int nframes, int64_t hop, int64_t mpad,
-                                                            int nsrc, float *__restrict__ bus0, float *__restrict__ bus1,
+// COLS: columns per tile (32, or 16 for R = 256 so that the workgroup stays at 256 threads: with 512 the
+// bus-fold variants need more registers than two waves per SIMD leave and spill).
+template <int R, int COLS, bool MIX, bool WRITE>
+__global__ __launch_bounds__(COLS *R / 16) void k_lf_inv(const c32 *__restrict__ A, int nframes, int64_t base, int64_t hop,
+                                                            int64_t mpad, int nsrc, float *__restrict__ bus0, float *__restrict__ bus1,
                                                             int64_t tl, const double *__restrict__ vol, float *__restrict__ out,
                                                             int64_t out_stride, int64_t out_len, const c32 *__restrict__ tab)
 {
@@ -185,8 +187,8 @@ __global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_inv(const c32 *__restric
     constexpr int R1 = FftPlan<R>::radix(1), NB = PT / R1;
     extern __shared__ __align__(16) unsigned char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
-    const int col = threadIdx.x & (LF_COLS - 1), j = threadIdx.x >> 5;
-    const int c = blockIdx.x * LF_COLS + col;
+    const int col = threadIdx.x & (COLS - 1), j = threadIdx.x / COLS;
+    const int c = blockIdx.x * COLS + col;
     const int frame = blockIdx.y;
     const TwTables<R> tw = lf_col_tables<R>(tab);
     // inputs k1 = j + t*NTF: conj of exp(-2*pi*i*c*k1/Nc) = conj(W^(c*j)) * conj(W^(c*NTF))^t
@@ -201,21 +203,32 @@ __global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_inv(const c32 *__restric
     c32 pf[NB];
     static_for<0, NB>([&](auto u) { pf[u] = cconj(cmul(tab[LF_ROW + j + int(u) * NTF], tab[LF_COL + c])); });
     // sample pair of output (u, t): frame position 2m, kept when it lies in the frame's last hop samples
-    const int64_t obase = (int64_t)frame * hop - mpad + 2 * (int64_t)c;
+    const int64_t obase = base + (int64_t)frame * hop - mpad + 2 * (int64_t)c;
     auto out_index = [&](int r) { return obase + 2 * (int64_t)r * C; };  // global sample index (valid when >= frame*hop)
-    const int64_t first = (int64_t)frame * hop;
+    const int64_t first = base + (int64_t)frame * hop;
 
+    // A tile access = a base that is the same in every lane (job, frame, row group: scalar registers, passed
+    // through an empty asm so that the optimiser does not fold it into sixteen per-lane 64-bit offsets that
+    // would live across the source loop) + one per-lane offset.
+    const c32 *__restrict__ At = A + (j * C + c);
     auto fetch = [&](int job, c32 *v) {
-        const c32 *a = A + ((int64_t)job * nframes + frame) * Nc + c;
-        static_for<0, PT>([&](auto t) { v[t] = ld_nt(a + (int64_t)(j + int(t) * NTF) * C); });
+        static_for<0, PT>([&](auto t) {
+            int64_t at = ((int64_t)job * nframes + frame) * Nc + (int64_t)(int(t) * NTF) * C;
+            asm volatile("" : "+s"(at));
+            v[t] = ld_nt(At + at);
+        });
     };
+    // the second stage's looked-up twiddles, taken out of the source loop (a table load inside it would
+    // make every pass wait for the next source's tile, which is in flight behind it)
+    c32 w1[NB];
+    stage_first_powers<R, 1, true>(j, w1, tw);
     auto transform = [&](c32 *v) {
         static_for<0, PT>([&](auto t) { v[t] = cmul(v[t], tin[t]); });
         stage_compute<R, 0, true>(j, v, tw);
-        stage_store<R, 0, true>(j, v, [&](int i, c32 val, int, int) { lds[i * LF_COLS + col] = val; });
+        stage_store<R, 0, true>(j, v, [&](int i, c32 val, int, int) { lds[i * COLS + col] = val; });
         __syncthreads();
-        stage_load<R, 1>(j, v, [&](int i) { return lds[i * LF_COLS + col]; });
-        stage_compute<R, 1, true>(j, v, tw);
+        stage_load<R, 1>(j, v, [&](int i) { return lds[i * COLS + col]; });
+        stage_compute_with<R, 1, true>(v, w1);
     };
 
     if constexpr (!MIX) {
@@ -260,29 +273,39 @@ __global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_inv(const c32 *__restric
                 }
             }
         });
-        auto transform_fold = [&](c32 *v, int src, double g) {
-            transform(v);
-            float *y = WRITE ? out + (int64_t)(2 * src + ch) * out_stride : nullptr;
-            const bool al = WRITE && (reinterpret_cast<uintptr_t>(y) & 7) == 0;
-            stage_store<R, 1, true>(j, v, [&](int r, c32 val, auto t, auto u) {
-                val = cmul(val, mul_w32<int(t) * (256 / R), true>(pf[u]));
-                const int64_t o = out_index(r);
-                if (o >= first) {
-                    if constexpr (WRITE) {
-                        if (al && o + 1 < out_len) {
-                            st_nt(reinterpret_cast<c32 *>(y + o), val);
-                        } else {
-                            if (o < out_len) y[o] = val.x;
-                            if (o + 1 < out_len) y[o + 1] = val.y;
-                        }
-                    }
-                    constexpr int slot = int(u) * R1 + int(t);
-                    acc[slot].x = mix_fold(acc[slot].x, val.x, g);
-                    acc[slot].y = mix_fold(acc[slot].y, val.y, g);
-                }
-            });
-            __syncthreads();  // every lane is done reading LDS before the next transform overwrites it
-        };
+        // A source's samples go out through a buffer descriptor over the part of its result that this
+        // frame owns, [first, first + room): the store is one unconditional instruction per pair (the
+        // hardware drops lanes whose byte offset, negative ones wrapped, lies outside the descriptor), so
+        // the wait for the next source's tile counts the stores issued behind its loads instead of
+        // waiting for them too.  A pair that straddles the result's end (odd length) takes the `edge` path.
+        int64_t room = out_len - first;
+        if (room > hop) room = hop;
+        if (room < 0 || !WRITE) room = 0;
+        const uint32_t nrec = (uint32_t)(room & ~(int64_t)1) * 4u;
+        int ybo[NB];  // byte offset of output row j + u*NTF (t = 0) from `first`
+        static_for<0, NB>([&](auto u) { ybo[u] = (2 * (c + (j + int(u) * NTF) * C) - (int)mpad) * 4; });
+        // bit slot of `live`: the pair reaches the result or the bus; of `edge`: only its first sample is inside the result
+        uint32_t live = 0, edge = 0;
+        const int64_t lim = WRITE && out_len > tl ? out_len : tl;
+        each_out([&](auto slot, int64_t o) {
+            if (o >= first) {
+                if (o < lim) live |= 1u << int(slot);
+                if (WRITE && o + 1 == out_len) edge |= 1u << int(slot);
+            }
+        });
+        // pairs of a slot that is live in some lane of the wave are folded in every lane: accumulators of
+        // pairs outside the frame or the bus are never stored
+        uint32_t wl = 0;
+        static_for<0, PT>([&](auto slot) {
+            if (__builtin_amdgcn_ballot_w64((live >> int(slot)) & 1u) != 0) wl |= 1u << int(slot);
+        });
+        const uint32_t wlive = __builtin_amdgcn_readfirstlane(wl);
+        const bool any_edge = __builtin_amdgcn_ballot_w64(edge != 0) != 0;
+        // the input twiddles wait in LDS behind the exchange tile, one private slot per thread and point:
+        // 32 registers fewer across the source loop
+        constexpr int NT = COLS * R / 16;
+        c32 *tinL = lds + R * COLS + threadIdx.x;
+        static_for<0, PT>([&](auto t) { tinL[int(t) * NT] = tin[t]; });
         c32 v[PT], vn[PT];
         fetch(ch, vn);
 #pragma unroll 1
@@ -290,7 +313,29 @@ __global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_inv(const c32 *__restric
 #pragma unroll
             for (int i = 0; i < PT; i++) v[i] = vn[i];
             fetch(2 * (s + 1 < nsrc ? s + 1 : nsrc - 1) + ch, vn);  // clamped: always a valid tile
-            transform_fold(v, s, vol[s]);
+            const double g = vol[s];
+            static_for<0, PT>([&](auto t) { v[t] = cmul(v[t], tinL[int(t) * NT]); });
+            stage_compute<R, 0, true>(j, v, tw);
+            stage_store<R, 0, true>(j, v, [&](int i, c32 val, int, int) { lds[i * COLS + col] = val; });
+            __syncthreads();
+            stage_load<R, 1>(j, v, [&](int i) { return lds[i * COLS + col]; });
+            stage_compute_with<R, 1, true>(v, w1);
+            float *yb = WRITE ? out + (int64_t)(2 * s + ch) * out_stride + first : nullptr;
+            const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yb, 0, nrec, 0x00020000);
+            stage_store<R, 1, true>(j, v, [&](int, c32 val, auto t, auto u) {
+                constexpr int slot = int(u) * R1 + int(t);
+                if (wlive & (1u << slot)) {
+                    val = cmul(val, mul_w32<int(t) * (256 / R), true>(pf[u]));
+                    if constexpr (WRITE) {
+                        const int off = ybo[u] + 2 * C * 16 * 4 * int(t);
+                        __builtin_amdgcn_raw_buffer_store_b64(v2f{val.x, val.y}, yrs, off, 0, 2 /* non-temporal */);
+                        if (any_edge && (edge & (1u << slot))) yb[off >> 2] = val.x;
+                    }
+                    acc[slot].x = mix_fold(acc[slot].x, val.x, g);
+                    acc[slot].y = mix_fold(acc[slot].y, val.y, g);
+                }
+            });
+            __syncthreads();  // every lane is done reading LDS before the next transform overwrites it
         }
         each_out([&](auto slot, int64_t o) {
             if (o >= first) {
@@ -316,23 +361,24 @@ static hipError_t lf_lds(K kernel, size_t bytes)
 
 template <int R>
 static hipError_t lf_fwd_t(const float *in, int64_t in_stride, int64_t in_len, c32 *A, int nframes, int frames_run, int njobs,
-                           int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s)
+                           int64_t base, int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s)
 {
     const size_t lds = sizeof(c32) * R * LF_COLS;
     if (hipError_t e = lf_lds(k_lf_fwd<R>, lds)) return e;
     hipLaunchKernelGGL((k_lf_fwd<R>), dim3(LF_C / LF_COLS, frames_run, njobs), dim3(LF_COLS * R / 16), lds, s, in, in_stride, in_len,
-                       A, nframes, hop, mpad, tab);
+                       A, nframes, base, hop, mpad, tab);
     return hipGetLastError();
 }
 
 hipError_t launch_lf_fwd(int R, const float *in, int64_t in_stride, int64_t in_len, c32 *A, int nframes, int frames_run,
-                         int njobs, int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s)
+                         int njobs, int64_t base, int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s)
 {
     if (frames_run <= 0) return hipSuccess;
     if (nframes > 65535 || njobs > 65535) return hipErrorInvalidValue;
     switch (R) {
-    case 128: return lf_fwd_t<128>(in, in_stride, in_len, A, nframes, frames_run, njobs, hop, mpad, tab, s);
-    case 256: return lf_fwd_t<256>(in, in_stride, in_len, A, nframes, frames_run, njobs, hop, mpad, tab, s);
+    case 64: return lf_fwd_t<64>(in, in_stride, in_len, A, nframes, frames_run, njobs, base, hop, mpad, tab, s);
+    case 128: return lf_fwd_t<128>(in, in_stride, in_len, A, nframes, frames_run, njobs, base, hop, mpad, tab, s);
+    case 256: return lf_fwd_t<256>(in, in_stride, in_len, A, nframes, frames_run, njobs, base, hop, mpad, tab, s);
     }
     return hipErrorInvalidValue;
 }
@@ -351,23 +397,24 @@ hipError_t launch_lf_mid(bool hprep, int R, c32 *A, c32 *Hs, const int32_t *job_
 }
 
 template <int R>
-static hipError_t lf_inv_t(const c32 *A, int nframes, int frames_run, int njobs, int64_t hop, int64_t mpad, int nsrc, float *bus0, float *bus1,
+static hipError_t lf_inv_t(const c32 *A, int nframes, int frames_run, int njobs, int64_t base, int64_t hop, int64_t mpad, int nsrc, float *bus0, float *bus1,
                            int64_t tl, const double *vol, float *out, int64_t out_stride, int64_t out_len, const c32 *tab,
                            hipStream_t s)
 {
-    const size_t lds = sizeof(c32) * R * LF_COLS;
-    const dim3 block(LF_COLS * R / 16);
+    constexpr int COLS = R > 128 ? 16 : 32;
+    const size_t lds = sizeof(c32) * R * COLS * (bus0 ? 2 : 1);  // the bus-fold variants keep their input twiddles behind the tile
+    const dim3 block(COLS * R / 16);
     if (!bus0) {
-        if (hipError_t e = lf_lds(k_lf_inv<R, false, true>, lds)) return e;
-        hipLaunchKernelGGL((k_lf_inv<R, false, true>), dim3(LF_C / LF_COLS, frames_run, njobs), block, lds, s, A, nframes, hop, mpad,
+        if (hipError_t e = lf_lds(k_lf_inv<R, COLS, false, true>, lds)) return e;
+        hipLaunchKernelGGL((k_lf_inv<R, COLS, false, true>), dim3(LF_C / COLS, frames_run, njobs), block, lds, s, A, nframes, base, hop, mpad,
                            nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab);
     } else if (out) {
-        if (hipError_t e = lf_lds(k_lf_inv<R, true, true>, lds)) return e;
-        hipLaunchKernelGGL((k_lf_inv<R, true, true>), dim3(LF_C / LF_COLS, frames_run, 2), block, lds, s, A, nframes, hop, mpad, nsrc,
+        if (hipError_t e = lf_lds(k_lf_inv<R, COLS, true, true>, lds)) return e;
+        hipLaunchKernelGGL((k_lf_inv<R, COLS, true, true>), dim3(LF_C / COLS, frames_run, 2), block, lds, s, A, nframes, base, hop, mpad, nsrc,
                            bus0, bus1, tl, vol, out, out_stride, out_len, tab);
     } else {
-        if (hipError_t e = lf_lds(k_lf_inv<R, true, false>, lds)) return e;
-        hipLaunchKernelGGL((k_lf_inv<R, true, false>), dim3(LF_C / LF_COLS, frames_run, 2), block, lds, s, A, nframes, hop, mpad, nsrc,
+        if (hipError_t e = lf_lds(k_lf_inv<R, COLS, true, false>, lds)) return e;
+        hipLaunchKernelGGL((k_lf_inv<R, COLS, true, false>), dim3(LF_C / COLS, frames_run, 2), block, lds, s, A, nframes, base, hop, mpad, nsrc,
                            bus0, bus1, tl, vol, out, out_stride, out_len, tab);
     }
     return hipGetLastError();
@@ -375,15 +422,16 @@ static hipError_t lf_inv_t(const c32 *A, int nframes, int frames_run, int njobs,
 
 // bus0 == nullptr: plain results for every job; otherwise the bus fold over nsrc stereo sources,
 // with the per-job results too when out != nullptr
-hipError_t launch_lf_inv(int R, const c32 *A, int nframes, int frames_run, int njobs, int64_t hop, int64_t mpad, int nsrc,
+hipError_t launch_lf_inv(int R, const c32 *A, int nframes, int frames_run, int njobs, int64_t base, int64_t hop, int64_t mpad, int nsrc,
                          float *bus0, float *bus1, int64_t tl, const double *vol, float *out, int64_t out_stride,
                          int64_t out_len, const c32 *tab, hipStream_t s)
 {
     if (frames_run <= 0) return hipSuccess;
     if (nframes > 65535 || njobs > 65535) return hipErrorInvalidValue;
     switch (R) {
-    case 128: return lf_inv_t<128>(A, nframes, frames_run, njobs, hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab, s);
-    case 256: return lf_inv_t<256>(A, nframes, frames_run, njobs, hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab, s);
+    case 64: return lf_inv_t<64>(A, nframes, frames_run, njobs, base, hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab, s);
+    case 128: return lf_inv_t<128>(A, nframes, frames_run, njobs, base, hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab, s);
+    case 256: return lf_inv_t<256>(A, nframes, frames_run, njobs, base, hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab, s);
     }
     return hipErrorInvalidValue;
 }

@@ -75,7 +75,8 @@ wp_ir *wp_ir_create_dev(const float *ir_dev, int nch, int64_t ch_stride, int64_t
 void wp_ir_destroy(wp_ir *ir);
 /* which: 0 M, 1 L, 2 channels, 3 partition size B, 4 partitions P, 5 result length L+M,
  * 6 reference FFT length, 7 device bytes of spectra, 8 handles sharing them,
- * 9 frame length of the long-frame form (0: results of L+M samples use the partitioned form). */
+ * 9 frame length of the long-frame form's first run of frames (0: results of L+M samples use the
+ * partitioned form), 10 runs of equal frames, 11 frame samples per job over all runs. */
 int64_t wp_ir_info(const wp_ir *ir, int which);
 
 /* ---- convolution: lib/convolve.js:564-586 fftConvolution(...) -> go(input) - */
@@ -157,8 +158,10 @@ int wp_conv_profile_read(wp_conv *c, float *ms3);
 /* Geometry of a plan: which = 0 jobs, 1 output blocks T, 2 partition size B,
  * 3 partitions P (padded), 4 blocks per MAC time chunk, 5 whether the small-batch
  * (gather) form of the spectral multiply-accumulate is in use, 6 whether the plan
- * runs the long-frame form (then: 7 frame length in samples, 8 frames per job,
- * 9 samples a frame advances by). */
+ * runs the long-frame form (then, for its first run of equal frames: 7 frame length in
+ * samples, 8 frames per job, 9 samples a frame advances by; 10 number of runs, 11 frame
+ * samples per job over all runs; 16+4i.. 19+4i for run i: frame length, frames, advance,
+ * first output sample). */
 int64_t wp_conv_info(const wp_conv *c, int which);
 
 /* ---- block reverb: lib/impulse-reverb.js:10-21, impulse-reverb-stereo.js:11-30 */
@@ -313,6 +316,7 @@ double wp_bpm_from_beat_rate(double sample_rate, int64_t beat_rate);
 #define WP_TUNE_MAC_GROUP 1 /* partitions per multiply-accumulate pass: 4, 8, 12, 16, 24 */
 #define WP_TUNE_MAC_FORM 2  /* 1 streaming delay-line kernel, 2 small-batch gather kernel */
 #define WP_TUNE_CONV_FORM 5 /* convolution form of IR handles created afterwards: 1 partitioned, 2 long-frame where the sizes allow */
+#define WP_TUNE_LF_RUNS 6   /* long-frame form: at most this many runs of equal frames per result (1..3; 1 = one frame size) */
 #define WP_TUNE_FWD_FORM 4  /* forward transform: 1 one segment per workgroup, 2 two (the default; takes effect at once) */
 #define WP_TUNE_POOL_MB 3   /* cap of the wp_buf recycling pool in MiB (default 2048; 0 disables it) */
 int wp_tune(int what, int64_t value);

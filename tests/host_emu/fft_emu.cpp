@@ -147,6 +147,8 @@ int main()
         printf("%-28s rel err %.3e %s\n", name, e, e < tol ? "ok" : "FAIL"); \
         if (!(e < tol)) bad++;                                 \
     } while (0)
+    CHECK("fft 64 fwd", (test_fft<64, false>()), 2e-6);
+    CHECK("fft 64 inv", (test_fft<64, true>()), 2e-6);
     CHECK("fft 128 fwd", (test_fft<128, false>()), 2e-6);   // the column transforms of the long-frame convolution
     CHECK("fft 128 inv", (test_fft<128, true>()), 2e-6);
     CHECK("fft 256 fwd", (test_fft<256, false>()), 2e-6);

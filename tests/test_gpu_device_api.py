@@ -443,25 +443,40 @@ def test_fused_paths_vs_oracle_all_plans(torch, oracle, L, M, tracks, per_track_
     assert torch.equal(bus.view(torch.int32), bus2.view(torch.int32))
 
 
-@pytest.mark.parametrize("L,M,tracks,frame", [(600000, 5000, 2, 524288), (1300000, 96000, 1, 524288), (900000, 300000, 1, 1048576)])
-def test_long_frame_form_vs_oracle(torch, oracle, L, M, tracks, frame):
+@pytest.mark.parametrize("L,M,tracks,cap,runs", [
+    (600000, 5000, 2, 0, [(262144, 3)]),                                   # three frames of 2^18
+    (1150001, 96000, 1, 1, [(524288, 3)]),                                 # one frame size only: 2^19; odd result length
+    (1300000, 96000, 1, 0, [(1048576, 1), (262144, 3)]),                   # a long frame, the rest in short ones
+    (1440000, 96000, 1, 0, [(1048576, 1), (524288, 1), (262144, 1)]),      # three frame sizes
+    (900000, 300000, 1, 0, [(1048576, 2)]),                                # M > 2^18: only 2^20 holds the kernel
+])
+def test_long_frame_form_vs_oracle(torch, oracle, L, M, tracks, cap, runs):
     """The long-frame form of the convolution (whole impulse response per frame, four-step transform)
     against the oracle: plain results with an odd output stride and a short input, the one-pass
     results + bus, the bus-only entry point, and the bus against wp_mix_dev of the written results
-    bit for bit.  Frames of 2^19 and 2^20 samples (the second because M > 2^18)."""
+    bit for bit.  A result is covered by up to three runs of equal frames (2^20, 2^19, 2^18 samples);
+    `cap` limits the number of runs (WP_TUNE_LF_RUNS)."""
     from dsp_amd import capi, device
     lib = capi.lib()
     njobs = 2 * tracks
     irs = np.stack([oracle.synth_ir(M, 800 + c) for c in range(2)])
     capi.check(lib.wp_tune(5, 2), "wp_tune")  # WP_TUNE_CONV_FORM: long-frame where the sizes allow
+    capi.check(lib.wp_tune(6, cap), "wp_tune")  # WP_TUNE_LF_RUNS
     try:
         ir = device.DeviceIR(torch.from_numpy(irs).cuda(), L)
     finally:
         lib.wp_tune(5, 0)
-    assert ir.info(9) == frame
+        lib.wp_tune(6, 0)
+    assert ir.info(9) == runs[0][0] and ir.info(10) == len(runs) and ir.info(11) == sum(f * n for f, n in runs)
     job_ch = [(j + 1) % 2 for j in range(njobs)]
     conv = device.BatchedConvolver(ir, job_ch)
-    assert lib.wp_conv_info(conv.handle, 6) == 1 and lib.wp_conv_info(conv.handle, 7) == frame
+    assert lib.wp_conv_info(conv.handle, 6) == 1 and lib.wp_conv_info(conv.handle, 10) == len(runs)
+    base = 0
+    for i, (frame, nfr) in enumerate(runs):
+        got_run = [lib.wp_conv_info(conv.handle, 16 + 4 * i + k) for k in range(4)]
+        assert got_run[:2] == [frame, nfr] and got_run[3] == base, (i, got_run)
+        base += nfr * got_run[2]
+    assert base >= L + M
     x = np.stack([oracle.synth_noise(L, 900 + j) for j in range(njobs)])
     xd = torch.from_numpy(x).cuda()
     kern = [oracle.fft_process_kernel(L, irs[c]) for c in range(2)]
