@@ -517,6 +517,10 @@ extern "C" int wp_tune(int what, int64_t value)
         if (value < 0 || value > 2) break;
         g_tune_form = (int)value;
         return WP_OK;
+    case WP_TUNE_MID_FORM:
+        if (value != 0 && value != 1 && value != 4 && value != 8 && value != 16) break;
+        set_mid_jobs(value == 0 ? 8 : value == 1 ? 0 : (int)value);
+        return WP_OK;
     case WP_TUNE_LF_RUNS:
         if (value < 0 || value > LF_MAX_SEG) break;
         g_tune_lf_runs = (int)value;

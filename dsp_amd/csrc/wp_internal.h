@@ -62,6 +62,7 @@ constexpr int LF_T256 = 0, LF_ROW = 256, LF_COL = 512, LF_FLO = 2560, LF_FHI = 3
 // nframes: frames per job in A (the stride); frames_run <= nframes: how many of them this launch handles
 hipError_t launch_lf_fwd(int R, const float *in, int64_t in_stride, int64_t in_len, c32 *A, int nframes, int frames_run,
                          int njobs, int64_t base, int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s);
+void set_mid_jobs(int jobs);  // WP_TUNE_MID_FORM
 // tab_row: the table block of the 2048-point plan (row transforms)
 hipError_t launch_lf_mid(bool hprep, int R, c32 *A, c32 *Hs, const int32_t *job_irch, int irch_all, int nframes,
                          int frames_run, int njobs, const c32 *tab, const c32 *tab_row, hipStream_t s);

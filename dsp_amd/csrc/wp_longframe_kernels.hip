@@ -170,6 +170,86 @@ __global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__rest
     stage_store<C, FftPlan<C>::NSTAGE - 1, true>(fi, v, [&](int i, c32 val, int, int) { st_nt(rowp + i, val); });
 }
 
+// The row pass for batches: a workgroup walks JB consecutive jobs of its row pair with the next job's
+// rows already on their way while the current ones are transformed, so the latency of the 32 KB it
+// streams per job is covered by its own work instead of by other workgroups.  Inside the loop nothing
+// else is loaded from global memory ahead of the kernel spectrum (a younger load's wait would also wait
+// for the rows in flight): the row plan's tables are copied to LDS, the split factors kept in registers.
+// Same arithmetic as k_lf_mid<false>.
+template <int JB>
+__global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const c32 *__restrict__ Hs,
+                                                     const int32_t *__restrict__ job_irch, int irch_all, int R, int nframes,
+                                                     int njobs, const c32 *__restrict__ tab, const c32 *__restrict__ tab_row)
+{
+    constexpr int C = LF_C, NT = C / 16, LAST = FftPlan<C>::NSTAGE - 1, NSL = plan_ns<C>(LAST);
+    static_assert(FftPlan<C>::radix(0) == 16 && FftPlan<C>::PT == 16, "one stage-0 butterfly per thread");
+    extern __shared__ __align__(16) unsigned char smem[];
+    c32 *lds = reinterpret_cast<c32 *>(smem);
+    c32 *tws = lds + 2 * C;
+    const int tid = threadIdx.x, half = tid >> 7, ft = tid & (NT - 1);
+    const int k1 = blockIdx.y, frame = blockIdx.z;
+    const int job0 = blockIdx.x * JB, jend = job0 + JB < njobs ? job0 + JB : njobs;
+    const int64_t Nc = (int64_t)R * C;
+    const int row = half ? R - 1 - k1 : k1;
+    c32 *ldsrow = lds + half * C;
+    const TwTables<C> tw = load_tables<C, true>(tab_row, tws, tid);  // first used behind the first exchange's barrier
+    // a row access = a base that is the same in every lane (job, frame, point group; kept in scalar registers by
+    // an empty asm, or the optimiser folds it into sixteen per-lane 64-bit offsets) + one per-lane offset
+    c32 *__restrict__ Arow = A + (int64_t)row * C;
+    auto fetch = [&](int job, c32 *v) {
+        static_for<0, 16>([&](auto t) {
+            int64_t at = ((int64_t)job * nframes + frame) * Nc + int(t) * (C / 16);
+            asm volatile("" : "+s"(at));
+            v[t] = ld_nt(Arow + ft + at);
+        });
+    };
+    const c32 wa = tab[LF_WA + k1];
+    c32 wk[C / 256];  // exp(-i*pi*(k+1/2)/Nc) of this thread's bins k = k1 + R*k2, k2 = tid + 256*q
+    static_for<0, C / 256>([&](auto q) { wk[q] = cmul(wa, tab[LF_WB + tid + 256 * int(q)]); });
+
+    c32 v[16], vn[16];
+    fetch(job0, vn);
+#pragma unroll 1
+    for (int job = job0; job < jend; job++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = vn[i];
+        if (job + 1 < jend) fetch(job + 1, vn);
+        const int irch = job_irch ? job_irch[job] : irch_all;
+        const c32 *ha = Hs + ((int64_t)irch * R + k1) * C;
+        const c32 *hb = Hs + ((int64_t)irch * R + (R - 1 - k1)) * C;
+        // the thread indices are hidden from the optimiser once per job (and once more between the two
+        // transforms): every LDS address and twiddle power derived from them would otherwise be computed
+        // once, ahead of the loop, and held in some 150 registers across it
+        int ff = ft, tl = tid;
+        asm volatile("" : "+v"(ff), "+v"(tl));
+        middle_stages<C, false>(ff, v, ldsrow, tw);
+        __syncthreads();  // every lane has taken its last-stage inputs out of LDS
+        stage_store<C, LAST, false>(ff, v, [&](int i, c32 val, int, int) { ldsrow[lds_pad(i)] = val; });
+        __syncthreads();
+        static_for<0, C / 256>([&](auto q) {
+            const int k2 = tl + 256 * int(q), p2 = C - 1 - k2;
+            const c32 za = lds[lds_pad(k2)], zb = lds[C + lds_pad(p2)];
+            const c32 wp = c32{-wk[q].x, wk[q].y};  // the partner's factor: -conj(wk)
+            const c32 xa = bin_split(za, zb, wk[q]), xb = bin_split(zb, za, wp);
+            const c32 ya = cmul(xa, ha[k2]), yb = cmul(xb, hb[p2]);
+            lds[lds_pad(k2)] = bin_unsplit(ya, yb, wk[q]);
+            lds[C + lds_pad(p2)] = bin_unsplit(yb, ya, wp);
+        });
+        __syncthreads();
+        int fi = ft;
+        asm volatile("" : "+v"(fi));
+        stage_load<C, 0>(fi, v, [&](int n) { return ldsrow[lds_pad(n)]; });
+        __syncthreads();  // all stage-0 inputs are in registers before the first exchange overwrites the row
+        middle_stages<C, true>(fi, v, ldsrow, tw);
+        stage_store<C, LAST, true>(fi, v, [&](int i, c32 val, auto t, auto) {
+            int64_t at = ((int64_t)job * nframes + frame) * Nc + int(t) * NSL;
+            asm volatile("" : "+s"(at));
+            st_nt(Arow + (i - int(t) * NSL) + at, val);
+        });
+        __syncthreads();  // the next job's first exchange writes the rows this one's last exchange read
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Inverse column pass + output (+ master-bus fold).  MIX: workgroup = (tile, frame) of ONE bus
 // channel (blockIdx.z), walking the stereo sources in order (jobs 2s + channel) with the next
@@ -319,22 +399,41 @@ __global__ __launch_bounds__(COLS *R / 16) void k_lf_inv(const c32 *__restrict__
             stage_store<R, 0, true>(j, v, [&](int i, c32 val, int, int) { lds[i * COLS + col] = val; });
             __syncthreads();
             stage_load<R, 1>(j, v, [&](int i) { return lds[i * COLS + col]; });
-            stage_compute_with<R, 1, true>(v, w1);
+            {
+                c32 wl[NB];  // hidden from the optimiser: the powers derived from them would otherwise live across the loop
+                static_for<0, NB>([&](auto u) {
+                    wl[u] = w1[u];
+                    asm volatile("" : "+v"(wl[u].x), "+v"(wl[u].y));
+                });
+                stage_compute_with<R, 1, true>(v, wl);
+            }
             float *yb = WRITE ? out + (int64_t)(2 * s + ch) * out_stride + first : nullptr;
             const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yb, 0, nrec, 0x00020000);
-            stage_store<R, 1, true>(j, v, [&](int, c32 val, auto t, auto u) {
-                constexpr int slot = int(u) * R1 + int(t);
-                if (wlive & (1u << slot)) {
-                    val = cmul(val, mul_w32<int(t) * (256 / R), true>(pf[u]));
-                    if constexpr (WRITE) {
-                        const int off = ybo[u] + 2 * C * 16 * 4 * int(t);
-                        __builtin_amdgcn_raw_buffer_store_b64(v2f{val.x, val.y}, yrs, off, 0, 2 /* non-temporal */);
-                        if (any_edge && (edge & (1u << slot))) yb[off >> 2] = val.x;
+            const float g32 = (float)g;
+            auto finish = [&](auto POW2) {  // post-twist, the source's samples out, the fold into the bus
+                stage_store<R, 1, true>(j, v, [&](int, c32 val, auto t, auto u) {
+                    constexpr int slot = int(u) * R1 + int(t);
+                    if (wlive & (1u << slot)) {
+                        val = cmul(val, mul_w32<int(t) * (256 / R), true>(pf[u]));
+                        if constexpr (WRITE) {
+                            const int off = ybo[u] + 2 * C * 16 * 4 * int(t);
+                            __builtin_amdgcn_raw_buffer_store_b64(v2f{val.x, val.y}, yrs, off, 0, 2 /* non-temporal */);
+                            if (any_edge && (edge & (1u << slot))) yb[off >> 2] = val.x;
+                        }
+                        if constexpr (decltype(POW2)::value) {
+                            acc[slot].x = mix_fold_pow2(acc[slot].x, val.x, g32);
+                            acc[slot].y = mix_fold_pow2(acc[slot].y, val.y, g32);
+                        } else {
+                            acc[slot].x = mix_fold(acc[slot].x, val.x, g);
+                            acc[slot].y = mix_fold(acc[slot].y, val.y, g);
+                        }
                     }
-                    acc[slot].x = mix_fold(acc[slot].x, val.x, g);
-                    acc[slot].y = mix_fold(acc[slot].y, val.y, g);
-                }
-            });
+                });
+            };
+            if (mix_gain_is_pow2(g))  // the same in every lane
+                finish(ic<1>{});
+            else
+                finish(ic<0>{});
             __syncthreads();  // every lane is done reading LDS before the next transform overwrites it
         }
         each_out([&](auto slot, int64_t o) {
@@ -352,6 +451,8 @@ __global__ __launch_bounds__(COLS *R / 16) void k_lf_inv(const c32 *__restrict__
 
 // ---------------------------------------------------------------------------
 // launchers
+static int g_mid_jobs = 8;  // batches of at least 16 jobs: the row pass that walks this many jobs per workgroup (0: one)
+void set_mid_jobs(int jobs) { g_mid_jobs = jobs; }
 template <class K>
 static hipError_t lf_lds(K kernel, size_t bytes)
 {
@@ -387,6 +488,21 @@ hipError_t launch_lf_mid(bool hprep, int R, c32 *A, c32 *Hs, const int32_t *job_
                          int frames_run, int njobs, const c32 *tab, const c32 *tab_row, hipStream_t s)
 {
     if (frames_run <= 0) return hipSuccess;
+    if (!hprep && njobs >= 16 && g_mid_jobs) {
+        const size_t ldsj = sizeof(c32) * (2 * LF_C + tw_table_points<LF_C>());
+        const int JB = g_mid_jobs;
+#define WP_MID_JOBS(N)                                                                                                        \
+    hipLaunchKernelGGL((k_lf_mid_jobs<N>), dim3((njobs + N - 1) / N, R / 2, frames_run), dim3(256), ldsj, s, A, Hs, job_irch, \
+                       irch_all, R, nframes, njobs, tab, tab_row)
+        if (JB == 4)
+            WP_MID_JOBS(4);
+        else if (JB == 16)
+            WP_MID_JOBS(16);
+        else
+            WP_MID_JOBS(8);
+#undef WP_MID_JOBS
+        return hipGetLastError();
+    }
     const size_t lds = sizeof(c32) * 2 * LF_C;
     const dim3 grid(njobs, R / 2, frames_run), block(256);
     if (hprep)
@@ -402,8 +518,25 @@ static hipError_t lf_inv_t(const c32 *A, int nframes, int frames_run, int njobs,
                            hipStream_t s)
 {
     constexpr int COLS = R > 128 ? 16 : 32;
-    const size_t lds = sizeof(c32) * R * COLS * (bus0 ? 2 : 1);  // the bus-fold variants keep their input twiddles behind the tile
+    size_t lds = sizeof(c32) * R * COLS * (bus0 ? 2 : 1);  // the bus-fold variants keep their input twiddles behind the tile
     const dim3 block(COLS * R / 16);
+    if (bus0 && out && block.x == 256) {
+        // (measured for the variant that also writes the sources' samples; the bus-only one gains from two per CU)
+        // A bus-fold workgroup is one long serial chain over the sources, and two of them on a CU run at half
+        // speed each: the pass takes (rounds of workgroups) x (workgroups per CU).  Two per CU fit; when one per
+        // CU needs fewer such units (e.g. 768 workgroups on 256 CUs: 3 against 2 x 2), ask for more LDS than
+        // two workgroups can share.
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+            if (ncu <= 0) ncu = 256;
+        }
+        const int64_t units = (int64_t)(LF_C / COLS) * frames_run * 2;
+        const int64_t one = (units + ncu - 1) / ncu, two = 2 * ((units + 2 * ncu - 1) / (2 * ncu));
+        if (one < two && lds < 84 * 1024) lds = 84 * 1024;
+    }
     if (!bus0) {
         if (hipError_t e = lf_lds(k_lf_inv<R, COLS, false, true>, lds)) return e;
         hipLaunchKernelGGL((k_lf_inv<R, COLS, false, true>), dim3(LF_C / COLS, frames_run, njobs), block, lds, s, A, nframes, base, hop, mpad,

@@ -137,3 +137,49 @@ def test_node_sample_file_ingestion():
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.startswith("ok sample-file")
+
+
+def test_power_of_two_gain_fold_is_one_rounding():
+    """The kernels fold a sample into the bus with ONE binary32 fused multiply-add when the gain is +-2^k,
+    instead of the reference's binary64 multiply, binary64 add and binary32 store
+    (src/mix-buffers.js:49-52).  The two are the same number: checked here with exact rational arithmetic
+    on operands chosen to sit on and around rounding ties, far-apart exponents and subnormals."""
+    from fractions import Fraction
+
+    def round_f32(fr):  # exact value -> nearest binary32, ties to even (what fmaf returns)
+        if fr == 0:
+            return 0.0
+        sign = -1 if fr < 0 else 1
+        a = abs(fr)
+        e = -149
+        while a / Fraction(2) ** e >= 2 ** 24:
+            e += 1
+        q = a / Fraction(2) ** e
+        n = q.numerator // q.denominator
+        rem = q - n
+        if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and n % 2 == 1):
+            n += 1
+        return float(sign * n * Fraction(2) ** e) if e + 24 <= 128 else sign * float("inf")
+
+    rng = np.random.default_rng(5)
+    cases = []
+    for _ in range(6000):
+        ea, eb = int(rng.integers(-140, 60)), int(rng.integers(-140, 60))
+        if rng.random() < 0.6:
+            eb = ea - int(rng.integers(18, 36))  # around the 24..29-bit gap where double rounding could bite
+        a = np.float32(np.ldexp(np.float32(rng.integers(1 << 23, 1 << 24)), ea - 23)) * (1 if rng.random() < 0.5 else -1)
+        m = int(rng.integers(1 << 23, 1 << 24))
+        if rng.random() < 0.5:
+            m = (1 << 23) | (1 << int(rng.integers(0, 23)))  # few bits set: exact ties after alignment
+        y = np.float32(np.ldexp(np.float32(m), eb - 23)) * (1 if rng.random() < 0.5 else -1)
+        k = int(rng.integers(-12, 4))
+        cases.append((a, y, np.ldexp(1.0, k) * (1 if rng.random() < 0.8 else -1)))
+    cases += [(np.float32(0.0), np.float32(1e-40), 0.5), (np.float32(-0.0), np.float32(0.0), 1.0), (np.float32(1.0), np.float32(2.0 ** -24), 1.0),
+              (np.float32(1.0), np.float32(-(2.0 ** -25)), 1.0), (np.float32(1e-38), np.float32(3e-39), 0.25)]
+    with np.errstate(all="ignore"):
+        for a, y, vol in cases:
+            if not (np.isfinite(a) and np.isfinite(y)):
+                continue
+            ref = np.float32(np.float64(a) + np.float64(y) * np.float64(vol))
+            one = np.float32(round_f32(Fraction(float(a)) + Fraction(float(y)) * Fraction(vol)))
+            assert ref.tobytes() == one.tobytes() or (ref == 0 and one == 0), (a, y, vol, ref, one)

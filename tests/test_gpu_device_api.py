@@ -516,6 +516,13 @@ def test_long_frame_form_vs_oracle(torch, oracle, L, M, tracks, cap, runs):
     oracle.mix_buffers(want_bus, *[[[want[2 * s], want[2 * s + 1]], 1, vol[s], 0] for s in range(tracks)])
     for ch in range(2):
         assert float(np.abs(bus[ch].cpu().numpy().astype(np.float64) - want_bus[ch]).max()) <= TOL
+    # gains that are powers of two take the one-instruction fold: same bits as wp_mix_dev's binary64 arithmetic
+    vol2 = [(-1.0 if s % 2 else 1.0) / (1 << (3 * s + 1)) for s in range(tracks)]
+    b4, b5, b6 = bus0.clone(), bus0.clone(), bus0.clone()
+    conv.run_and_mix(xd, out2, [b4[0], b4[1]], vol2)
+    conv.run_mix(xd, [b5[0], b5[1]], vol2)
+    device.DeviceMix([{"ch": [out2[2 * t], out2[2 * t + 1]], "rl": L + M, "sl": L + M, "vol": vol2[t]} for t in range(tracks)]).run([b6[0], b6[1]])
+    assert torch.equal(b4.view(torch.int32), b6.view(torch.int32)) and torch.equal(b5.view(torch.int32), b6.view(torch.int32))
 
 
 def test_mix_4096_aliased_stems_exact(torch):
