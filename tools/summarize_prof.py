@@ -41,6 +41,23 @@ for f in sorted(glob.glob(os.path.join(root, "stats", "**", "*kernel_trace.csv")
             continue
         d = [x[1] for x in sorted(v)]
         print("%-42s %s  -> steady avg %10.1f us" % (k, " ".join("%.0f" % x for x in d), sum(d[WARM:]) / len(d[WARM:])))
+    # With several runs of frames a kernel is launched once per run and step (and k_lf_mid_jobs<8> lists a long and a
+    # short launch alternately): per step, the launches of each kernel family added up.  A step starts at a launch of
+    # the forward kernel with the longest average duration.
+    fam = lambda k: "k_lf_inv" if k.startswith("k_lf_inv") else "k_lf_mid" if k.startswith("k_lf_mid") else k.split("<")[0]
+    firsts = [k for k in per if fam(k) in ("k_lf_fwd", "k_fft_fwd", "k_fft_fwd_pair") and len(per[k]) > WARM]
+    if firsts:
+        lead = max(firsts, key=lambda k: sum(x[1] for x in per[k]) / len(per[k]))
+        starts = sorted(x[0] for x in per[lead])
+        if len(starts) > WARM:
+            t0, nst = starts[WARM], len(starts) - WARM
+            print("# per step after the warm-up steps: launches of one kernel family added up (us)")
+            sums = defaultdict(float)
+            for k, v in per.items():
+                if any(t in k for t in ("k_lf_", "k_fft_fwd", "k_fft_inv", "k_mac", "k_mix<")):
+                    sums[fam(k)] += sum(x[1] for x in v if x[0] >= t0)
+            for k in sorted(sums):
+                print("%-42s %10.1f us per step" % (k, sums[k] / nst))
 
 print("# PMC (per launch averages)")
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
@@ -64,24 +81,28 @@ for k in sorted(acc):
 # doubled (checked here against k_mix and k_mac, whose read bytes are known exactly).
 import json
 traffic = {}
+tot = defaultdict(lambda: [0.0, 0.0])
 for k in acc:
     base = k.split("<")[0]
+    if base == "k_lf_mid_jobs":  # the row pass of batches
+        base = "k_lf_mid"
     if base == "k_fft_fwd_pair":  # the forward transform of the bench path (two segments per workgroup)
         base = "k_fft_fwd"
     if base == "k_fft_inv_mix":
         base = "k_fft_inv_mix_w" if "true" in k else "k_fft_inv_mix"
-    if base == "k_lf_inv":  # k_lf_inv<R, MIX, WRITE>
-        flags = k.replace(" ", "").split(",")[1:3]
+    if base == "k_lf_inv":  # k_lf_inv<R, COLS, MIX, WRITE>
+        flags = k.replace(" ", "").split(",")[2:4]
         base = "k_lf_inv" + ("_mix" if flags and flags[0].startswith("true") else "") + ("_w" if len(flags) > 1 and flags[0].startswith("true") and flags[1].startswith("true") else "")
     if base == "k_lf_mid" and "true" in k:
         continue  # the one-off kernel-spectrum launch
     if base in ("k_lf_fwd", "k_lf_mid", "k_lf_inv", "k_lf_inv_mix", "k_lf_inv_mix_w", "k_fft_fwd", "k_mac", "k_fft_inv", "k_fft_inv_mix", "k_fft_inv_mix_w", "k_mix") and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
-        f = peak[k]["FETCH_SIZE"]
-        w = peak[k]["WRITE_SIZE"]
-        if base in ("k_fft_fwd", "k_lf_fwd") and f < 1e5:
-            continue  # the one-off IR-partition launch, not the bench kernel
-        traffic[base] = int(2 * f * 1024 + w * 1024)
-print("# traffic bytes per launch (2*FETCH_SIZE + WRITE_SIZE):", traffic)
+        # the PMC passes run ONE bench step: every launch of the family added up (the runs of frames of the long-frame
+        # form are separate launches; the launches on the impulse response add a few megabytes)
+        tot[base][0] += acc[k]["FETCH_SIZE"][0]
+        tot[base][1] += acc[k]["WRITE_SIZE"][0]
+for base, (f, w) in tot.items():
+    traffic[base] = int(2 * f * 1024 + w * 1024)
+print("# traffic bytes per step (2*FETCH_SIZE + WRITE_SIZE), all launches of a kernel family:", traffic)
 # the profiled command is the default bench workload (tools/profile_gpu.sh)
 traffic["workload"] = {"tracks_per_gpu": 256, "frames": 2880000, "ir_len": 96000, "path": "onepass"}
 with open(os.path.join(root, "traffic.json"), "w") as fh:
