@@ -325,6 +325,7 @@ struct LfGeom {
     int64_t pts = 0;  // complex points per job over all runs
 };
 static int g_tune_lf_runs = 0;  // WP_TUNE_LF_RUNS: 0 = up to LF_MAX_SEG runs of frames, n = at most n
+static int g_tune_lf_ab = 0;    // WP_TUNE_LF_SPECTRA: 1 = plain kernel spectra even when the jobs share them
 static LfGeom choose_lf(int64_t L, int64_t M, int nch)
 {
     LfGeom best;
@@ -442,6 +443,7 @@ struct wp_ir {
     c32 *lf_Hs[LF_MAX_SEG];       // per run of frames: [nch][R][LF_C] real spectra of the zero-padded kernels, scaled; owned by this handle
     const c32 *lf_tab[LF_MAX_SEG];  // long-frame tables of each run's R
     const c32 *lf_tab_row; // tables of the 2048-point row transforms
+    bool lf_ab;            // lf_Hs holds (alpha, beta) coefficient pairs per bin (few kernels, shared by the jobs) instead of spectra
     int64_t bytes;
     wp_conv *single;   // lazily built 1-job plan for wp_convolve / wp_convolve_dev
     int single_ch;     // IR channel that plan currently names
@@ -518,8 +520,12 @@ extern "C" int wp_tune(int what, int64_t value)
         g_tune_form = (int)value;
         return WP_OK;
     case WP_TUNE_MID_FORM:
-        if (value != 0 && value != 1 && value != 4 && value != 8 && value != 16) break;
-        set_mid_jobs(value == 0 ? 8 : value == 1 ? 0 : (int)value);
+        if (value < 0 || value > 2) break;
+        set_mid_jobs(value == 1 ? 0 : 8);
+        return WP_OK;
+    case WP_TUNE_LF_SPECTRA:
+        if (value < 0 || value > 2) break;
+        g_tune_lf_ab = (int)value;
         return WP_OK;
     case WP_TUNE_LF_RUNS:
         if (value < 0 || value > LF_MAX_SEG) break;
@@ -588,6 +594,7 @@ static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, 
         ir->lf_tab[i] = nullptr;
     }
     ir->lf_tab_row = nullptr;
+    ir->lf_ab = nch <= 4 && g_tune_lf_ab != 1;
     auto free_lf = [&]() {
         for (auto &h : ir->lf_Hs) {
             if (h) (void)hipFree(h);
@@ -613,7 +620,7 @@ static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, 
         // kernel spectra of the long-frame form: the kernels as one "frame" each, through the same
         // column and row passes the signal takes, once per frame size
         const int R = ir->lf.seg[i].R;
-        const size_t lbytes = sizeof(c32) * (size_t)nch * R * LF_C;
+        const size_t lbytes = sizeof(c32) * (size_t)nch * R * LF_C;  // of the transform; the coefficient form stores twice that
         c32 *tmpA = nullptr;
         hipError_t e = hipSuccess;
         if (get_lf_tables(dev, R, &ir->lf_tab[i]) != WP_OK || get_tables(dev, LF_C, &ir->lf_tab_row) != WP_OK) {
@@ -621,9 +628,9 @@ static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, 
             delete ir;
             return nullptr;
         }
-        if ((e = hipMalloc((void **)&ir->lf_Hs[i], lbytes)) == hipSuccess) e = hipMalloc((void **)&tmpA, lbytes);
+        if ((e = hipMalloc((void **)&ir->lf_Hs[i], lbytes * (ir->lf_ab ? 2 : 1))) == hipSuccess) e = hipMalloc((void **)&tmpA, lbytes);
         if (e == hipSuccess) e = launch_lf_fwd(R, ir_dev, ch_stride, M, tmpA, 1, 1, nch, 0, 0, 0, ir->lf_tab[i], s);
-        if (e == hipSuccess) e = launch_lf_mid(true, R, tmpA, ir->lf_Hs[i], nullptr, 0, 1, 1, nch, ir->lf_tab[i], ir->lf_tab_row, s);
+        if (e == hipSuccess) e = launch_lf_mid(true, ir->lf_ab, R, tmpA, ir->lf_Hs[i], nullptr, 0, 1, 1, nch, ir->lf_tab[i], ir->lf_tab_row, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (tmpA) (void)hipFree(tmpA);
         if (e != hipSuccess) {
@@ -632,7 +639,7 @@ static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, 
             delete ir;
             return nullptr;
         }
-        ir->bytes += (int64_t)lbytes;
+        ir->bytes += (int64_t)lbytes * (ir->lf_ab ? 2 : 1);
     }
     if (hashes) {
         ir->key = IrKey{dev, nch, ir->B, M, L, hashes[0], hashes[1]};
@@ -1013,7 +1020,7 @@ static int conv_front_lf(wp_conv *c, const float *in_dev, int64_t in_stride, int
     if (c->prof) HIPCHK(hipEventRecord(c->ev[1], s));
     for (int i = 0; i < ir->lf.nseg; i++) {
         const LfSeg &g = ir->lf.seg[i];
-        HIPCHK(launch_lf_mid(false, g.R, lf_seg_A(c, i), ir->lf_Hs[i], c->job_irch, c->irch_all, g.nframes, lf_frames_run(g, limit),
+        HIPCHK(launch_lf_mid(false, ir->lf_ab, g.R, lf_seg_A(c, i), ir->lf_Hs[i], c->job_irch, c->irch_all, g.nframes, lf_frames_run(g, limit),
                              c->njobs, ir->lf_tab[i], ir->lf_tab_row, s));
     }
     if (c->prof) HIPCHK(hipEventRecord(c->ev[2], s));

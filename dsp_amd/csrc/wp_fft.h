@@ -194,6 +194,30 @@ WP_HD int lds_pad(int i) { return i ^ ((i >> 4) & 15); }
 template <int B>
 constexpr int lds_points() { return B; }
 
+// Second layout, for kernels whose instruction count matters more than the last LDS conflict: one pad
+// element per 32, position i + i/32.  The padded position of base + delta follows from the base's by a
+// compile-time constant for every access pattern of a plan whose stage-0 radix is 16 (checked for all
+// threads by tests/host_emu/fft_emu.cpp), so an exchange costs one address computation per butterfly and
+// immediate offsets, where the XOR layout costs two instructions per element.  Runs of 32 consecutive
+// elements stay conflict-free; the stage-0 stores (stride 16) become two-way conflicted.
+WP_HD int lds_pad32(int i) { return i + (i >> 5); }
+template <int B>
+constexpr int lds_points32() { return B + B / 32; }
+// stage_store<B, S>: i = base + t*NS  ->  lds_pad32(i) = lds_pad32(base) + pad32_store_k<NS>(t)
+template <int NS>
+constexpr int pad32_store_k(int t)
+{
+    static_assert(NS == 1 || NS == 16 || NS % 32 == 0, "store stride");
+    return NS == 1 ? t : NS == 16 ? 16 * t + t / 2 : NS * t + NS * t / 32;
+}
+// stage_load<B, S>: n = j + t*(B/R), B/R a multiple of 32
+template <int STRIDE>
+constexpr int pad32_load_k(int t)
+{
+    static_assert(STRIDE % 32 == 0, "load stride");
+    return STRIDE * t + STRIDE * t / 32;
+}
+
 // Twiddle tables for one B (all f32 roundings of f64 values, built on the host):
 //   t256[a] = exp(-2*pi*i*a/256)        a < 256   (stages whose Ns*R <= 256)
 //   tlo[a]  = exp(-2*pi*i*a/B)          a < 256
@@ -233,6 +257,16 @@ WP_HD void stage_load(int tid, c32 *v, Src &&src)
     static_for<0, NB>([&](auto u) {
         const int j = tid + u * NT;
         static_for<0, R>([&](auto t) { v[u * R + t] = src(j + t * (B / R)); });
+    });
+}
+// the same with the position in the butterfly passed on: v[u*R + t] = src(j, t, u), element j + t*B/R
+template <int B, int S, class Src>
+WP_HD void stage_load_t(int tid, c32 *v, Src &&src)
+{
+    constexpr int PT = FftPlan<B>::PT, R = FftPlan<B>::radix(S), NT = B / PT, NB = PT / R;
+    static_for<0, NB>([&](auto u) {
+        const int j = tid + u * NT;
+        static_for<0, R>([&](auto t) { v[u * R + t] = src(j, t, u); });
     });
 }
 // compute: twiddle + DFT_R, in registers.  One table lookup per butterfly, then

@@ -64,7 +64,8 @@ hipError_t launch_lf_fwd(int R, const float *in, int64_t in_stride, int64_t in_l
                          int njobs, int64_t base, int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s);
 void set_mid_jobs(int jobs);  // WP_TUNE_MID_FORM
 // tab_row: the table block of the 2048-point plan (row transforms)
-hipError_t launch_lf_mid(bool hprep, int R, c32 *A, c32 *Hs, const int32_t *job_irch, int irch_all, int nframes,
+// ab: Hs holds (alpha, beta) coefficient pairs, 16 bytes per bin (kernel spectra shared by the jobs), instead of spectra
+hipError_t launch_lf_mid(bool hprep, bool ab, int R, c32 *A, c32 *Hs, const int32_t *job_irch, int irch_all, int nframes,
                          int frames_run, int njobs, const c32 *tab, const c32 *tab_row, hipStream_t s);
 // bus0 == nullptr: plain results for every job; otherwise the bus fold over nsrc stereo sources (jobs 2s, 2s+1),
 // with the per-job results too when out != nullptr

@@ -74,6 +74,26 @@ __device__ __forceinline__ void middle_stages(int tid, c32 *v, c32 *lds, const T
     });
 }
 
+// middle_stages on the one-pad-per-32 layout (lds_pad32): every LDS address is the butterfly's padded base
+// plus a compile-time constant
+template <int B, bool INV>
+__device__ __forceinline__ void middle_stages32(int tid, c32 *v, c32 *lds, const TwTables<B> &tw)
+{
+    constexpr int LAST = FftPlan<B>::NSTAGE - 1;
+    stage_compute<B, 0, INV>(tid, v, tw);
+    static_for<1, LAST + 1>([&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        constexpr int NSP = plan_ns<B>(S - 1), STRIDE = B / FftPlan<B>::radix(S);
+        stage_store<B, S - 1, INV>(tid, v, [&](int i, c32 val, auto t, auto) {
+            lds[lds_pad32(i - int(t) * NSP) + pad32_store_k<NSP>(int(t))] = val;
+        });
+        __syncthreads();
+        stage_load_t<B, S>(tid, v, [&](int j, auto t, auto) { return lds[lds_pad32(j) + pad32_load_k<STRIDE>(int(t))]; });
+        if constexpr (S < LAST) __syncthreads();  // the next store reuses the buffer
+        stage_compute<B, S, INV>(tid, v, tw);
+    });
+}
+
 // master-bus fold of one sample (src/mix-buffers.js:49-52): binary64 multiply, binary64 add, binary32 store
 __device__ __forceinline__ float mix_fold(float acc, float y, double vol)
 {

@@ -114,7 +114,26 @@ __global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_fwd(const float *__restr
 // transforms of 128 threads each).  HPREP: the rows are an impulse response's; store its real
 // spectrum scaled by 1/(8*Nc) (the factors 2 of split and unsplit and the inverse transform's Nc)
 // and stop.
-template <bool HPREP>
+//
+// AB (kernel spectra shared by the jobs, i.e. read from cache): the chain split -> product -> unsplit of a
+// bin pair is linear in (za, conj zb), and with w = exp(-i*theta) its coefficients collapse to
+//   Ya = alpha_a*za + beta_a*conj(zb),   alpha_a = 2(1 - sin)*Ha + 2(1 + sin)*conj(Hb),  beta_a = 2i*cos*(Ha - conj(Hb))
+//   Yb = alpha_b*zb + beta_b*conj(za),   alpha_b = 2(1 - sin)*Hb + 2(1 + sin)*conj(Ha),  beta_b = -conj(beta_a)
+// so the spectra are stored as (alpha, beta) per bin (16 bytes) and a pair costs 16 instructions instead of 44.
+// Kernel spectra that every job reads for itself from HBM keep the 8-byte form.
+struct alignas(16) c32x2 {
+    c32 a, b;
+};
+// alpha*z + beta*conj(zp)
+__device__ __forceinline__ c32 lf_pair_product(c32x2 h, c32 z, c32 zp)
+{
+    c32 y;
+    y.x = fmaf(h.b.y, zp.y, fmaf(h.b.x, zp.x, fmaf(h.a.x, z.x, -(h.a.y * z.y))));
+    y.y = fmaf(-h.b.x, zp.y, fmaf(h.b.y, zp.x, fmaf(h.a.x, z.y, h.a.y * z.x)));
+    return y;
+}
+
+template <bool HPREP, bool AB>
 __global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__restrict__ Hs, const int32_t *__restrict__ job_irch,
                                                 int irch_all, int R, int nframes, const c32 *__restrict__ tab,
                                                 const c32 *__restrict__ tab_row)
@@ -134,8 +153,8 @@ __global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__rest
     c32 v[16];
     stage_load<C, 0>(ft, v, [&](int n) { return ld_nt(rowp + n); });
     const int irch = HPREP ? job : (job_irch ? job_irch[job] : irch_all);
-    c32 *ha = Hs + ((int64_t)irch * R + k1) * C;
-    c32 *hb = Hs + ((int64_t)irch * R + (R - 1 - k1)) * C;
+    c32 *ha = Hs + ((int64_t)irch * R + k1) * C * (AB ? 2 : 1);
+    c32 *hb = Hs + ((int64_t)irch * R + (R - 1 - k1)) * C * (AB ? 2 : 1);
     middle_stages<C, false>(ft, v, ldsrow, tw);
     __syncthreads();  // every lane has taken its last-stage inputs out of LDS
     stage_store<C, FftPlan<C>::NSTAGE - 1, false>(ft, v, [&](int i, c32 val, int, int) { ldsrow[lds_pad(i)] = val; });
@@ -148,16 +167,34 @@ __global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__rest
     for (int q = 0; q < C / 256; q++) {
         const int k2 = tid + 256 * q, p2 = C - 1 - k2;
         const c32 za = lds[lds_pad(k2)], zb = lds[C + lds_pad(p2)];
-        const c32 wk = cmul(wa, tab[LF_WB + k2]);  // exp(-i*pi*(k+1/2)/Nc)
-        const c32 wp = c32{-wk.x, wk.y};          // the partner's: -conj(wk)
-        const c32 xa = bin_split(za, zb, wk), xb = bin_split(zb, za, wp);
-        if (HPREP) {
-            ha[k2] = c32{xa.x * scale, xa.y * scale};
-            hb[p2] = c32{xb.x * scale, xb.y * scale};
+        if constexpr (!HPREP && AB) {
+            const c32x2 pa = reinterpret_cast<const c32x2 *>(ha)[k2], pb = reinterpret_cast<const c32x2 *>(hb)[p2];
+            lds[lds_pad(k2)] = lf_pair_product(pa, za, zb);
+            lds[C + lds_pad(p2)] = lf_pair_product(pb, zb, za);
         } else {
-            const c32 ya = cmul(xa, ha[k2]), yb = cmul(xb, hb[p2]);
-            lds[lds_pad(k2)] = bin_unsplit(ya, yb, wk);
-            lds[C + lds_pad(p2)] = bin_unsplit(yb, ya, wp);
+            const c32 wk = cmul(wa, tab[LF_WB + k2]);  // exp(-i*pi*(k+1/2)/Nc)
+            const c32 wp = c32{-wk.x, wk.y};          // the partner's: -conj(wk)
+            const c32 xa = bin_split(za, zb, wk), xb = bin_split(zb, za, wp);
+            if constexpr (HPREP) {
+                const c32 a = c32{xa.x * scale, xa.y * scale}, b = c32{xb.x * scale, xb.y * scale};
+                if constexpr (AB) {
+                    const float sn = -wk.y, cs = wk.x, m = 2.0f * (1.0f - sn), p = 2.0f * (1.0f + sn);
+                    c32x2 pa, pb;
+                    pa.a = c32{fmaf(m, a.x, p * b.x), fmaf(m, a.y, -(p * b.y))};
+                    pb.a = c32{fmaf(m, b.x, p * a.x), fmaf(m, b.y, -(p * a.y))};
+                    pa.b = c32{-2.0f * cs * (a.y + b.y), 2.0f * cs * (a.x - b.x)};  // 2i*cos*(Ha - conj(Hb))
+                    pb.b = c32{-pa.b.x, pa.b.y};                                    // -conj(beta_a)
+                    reinterpret_cast<c32x2 *>(ha)[k2] = pa;
+                    reinterpret_cast<c32x2 *>(hb)[p2] = pb;
+                } else {
+                    ha[k2] = a;
+                    hb[p2] = b;
+                }
+            } else {
+                const c32 ya = cmul(xa, ha[k2]), yb = cmul(xb, hb[p2]);
+                lds[lds_pad(k2)] = bin_unsplit(ya, yb, wk);
+                lds[C + lds_pad(p2)] = bin_unsplit(yb, ya, wp);
+            }
         }
     }
     if (HPREP) return;
@@ -176,7 +213,7 @@ __global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__rest
 // else is loaded from global memory ahead of the kernel spectrum (a younger load's wait would also wait
 // for the rows in flight): the row plan's tables are copied to LDS, the split factors kept in registers.
 // Same arithmetic as k_lf_mid<false>.
-template <int JB>
+template <int JB, bool AB>
 __global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const c32 *__restrict__ Hs,
                                                      const int32_t *__restrict__ job_irch, int irch_all, int R, int nframes,
                                                      int njobs, const c32 *__restrict__ tab, const c32 *__restrict__ tab_row)
@@ -185,13 +222,14 @@ __global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const 
     static_assert(FftPlan<C>::radix(0) == 16 && FftPlan<C>::PT == 16, "one stage-0 butterfly per thread");
     extern __shared__ __align__(16) unsigned char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
-    c32 *tws = lds + 2 * C;
+    constexpr int CP = lds_points32<C>();  // a row in LDS: one pad element per 32 (lds_pad32)
+    c32 *tws = lds + 2 * CP;
     const int tid = threadIdx.x, half = tid >> 7, ft = tid & (NT - 1);
     const int k1 = blockIdx.y, frame = blockIdx.z;
     const int job0 = blockIdx.x * JB, jend = job0 + JB < njobs ? job0 + JB : njobs;
     const int64_t Nc = (int64_t)R * C;
     const int row = half ? R - 1 - k1 : k1;
-    c32 *ldsrow = lds + half * C;
+    c32 *ldsrow = lds + half * CP;
     const TwTables<C> tw = load_tables<C, true>(tab_row, tws, tid);  // first used behind the first exchange's barrier
     // a row access = a base that is the same in every lane (job, frame, point group; kept in scalar registers by
     // an empty asm, or the optimiser folds it into sixteen per-lane 64-bit offsets) + one per-lane offset
@@ -204,8 +242,8 @@ __global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const 
         });
     };
     const c32 wa = tab[LF_WA + k1];
-    c32 wk[C / 256];  // exp(-i*pi*(k+1/2)/Nc) of this thread's bins k = k1 + R*k2, k2 = tid + 256*q
-    static_for<0, C / 256>([&](auto q) { wk[q] = cmul(wa, tab[LF_WB + tid + 256 * int(q)]); });
+    c32 wk[AB ? 1 : C / 256];  // exp(-i*pi*(k+1/2)/Nc) of this thread's bins k = k1 + R*k2, k2 = tid + 256*q
+    if constexpr (!AB) static_for<0, C / 256>([&](auto q) { wk[q] = cmul(wa, tab[LF_WB + tid + 256 * int(q)]); });
 
     c32 v[16], vn[16];
     fetch(job0, vn);
@@ -215,32 +253,43 @@ __global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const 
         for (int i = 0; i < 16; i++) v[i] = vn[i];
         if (job + 1 < jend) fetch(job + 1, vn);
         const int irch = job_irch ? job_irch[job] : irch_all;
-        const c32 *ha = Hs + ((int64_t)irch * R + k1) * C;
-        const c32 *hb = Hs + ((int64_t)irch * R + (R - 1 - k1)) * C;
+        const c32 *ha = Hs + ((int64_t)irch * R + k1) * C * (AB ? 2 : 1);
+        const c32 *hb = Hs + ((int64_t)irch * R + (R - 1 - k1)) * C * (AB ? 2 : 1);
         // the thread indices are hidden from the optimiser once per job (and once more between the two
         // transforms): every LDS address and twiddle power derived from them would otherwise be computed
         // once, ahead of the loop, and held in some 150 registers across it
         int ff = ft, tl = tid;
         asm volatile("" : "+v"(ff), "+v"(tl));
-        middle_stages<C, false>(ff, v, ldsrow, tw);
+        middle_stages32<C, false>(ff, v, ldsrow, tw);
         __syncthreads();  // every lane has taken its last-stage inputs out of LDS
-        stage_store<C, LAST, false>(ff, v, [&](int i, c32 val, int, int) { ldsrow[lds_pad(i)] = val; });
+        stage_store<C, LAST, false>(ff, v, [&](int i, c32 val, auto t, auto) {
+            ldsrow[lds_pad32(i - int(t) * NSL) + pad32_store_k<NSL>(int(t))] = val;
+        });
         __syncthreads();
+        // bins k2 = tl + 256*q of row k1 and their partners C-1-k2 of the other row: 264 padded positions per q
+        c32 *za_p = lds + lds_pad32(tl), *zb_p = lds + CP + lds_pad32(C - 1 - tl);
         static_for<0, C / 256>([&](auto q) {
             const int k2 = tl + 256 * int(q), p2 = C - 1 - k2;
-            const c32 za = lds[lds_pad(k2)], zb = lds[C + lds_pad(p2)];
-            const c32 wp = c32{-wk[q].x, wk[q].y};  // the partner's factor: -conj(wk)
-            const c32 xa = bin_split(za, zb, wk[q]), xb = bin_split(zb, za, wp);
-            const c32 ya = cmul(xa, ha[k2]), yb = cmul(xb, hb[p2]);
-            lds[lds_pad(k2)] = bin_unsplit(ya, yb, wk[q]);
-            lds[C + lds_pad(p2)] = bin_unsplit(yb, ya, wp);
+            c32 &za_s = za_p[264 * int(q)], &zb_s = zb_p[-264 * int(q)];
+            const c32 za = za_s, zb = zb_s;
+            if constexpr (AB) {
+                const c32x2 pa = reinterpret_cast<const c32x2 *>(ha)[k2], pb = reinterpret_cast<const c32x2 *>(hb)[p2];
+                za_s = lf_pair_product(pa, za, zb);
+                zb_s = lf_pair_product(pb, zb, za);
+            } else {
+                const c32 wp = c32{-wk[q].x, wk[q].y};  // the partner's factor: -conj(wk)
+                const c32 xa = bin_split(za, zb, wk[q]), xb = bin_split(zb, za, wp);
+                const c32 ya = cmul(xa, ha[k2]), yb = cmul(xb, hb[p2]);
+                za_s = bin_unsplit(ya, yb, wk[q]);
+                zb_s = bin_unsplit(yb, ya, wp);
+            }
         });
         __syncthreads();
         int fi = ft;
         asm volatile("" : "+v"(fi));
-        stage_load<C, 0>(fi, v, [&](int n) { return ldsrow[lds_pad(n)]; });
+        stage_load_t<C, 0>(fi, v, [&](int j, auto t, auto) { return ldsrow[lds_pad32(j) + pad32_load_k<C / 16>(int(t))]; });
         __syncthreads();  // all stage-0 inputs are in registers before the first exchange overwrites the row
-        middle_stages<C, true>(fi, v, ldsrow, tw);
+        middle_stages32<C, true>(fi, v, ldsrow, tw);
         stage_store<C, LAST, true>(fi, v, [&](int i, c32 val, auto t, auto) {
             int64_t at = ((int64_t)job * nframes + frame) * Nc + int(t) * NSL;
             asm volatile("" : "+s"(at));
@@ -451,7 +500,7 @@ __global__ __launch_bounds__(COLS *R / 16) void k_lf_inv(const c32 *__restrict__
 
 // ---------------------------------------------------------------------------
 // launchers
-static int g_mid_jobs = 8;  // batches of at least 16 jobs: the row pass that walks this many jobs per workgroup (0: one)
+static int g_mid_jobs = 8;  // batches of at least 16 jobs: the row pass that walks 8 jobs per workgroup (0: one job)
 void set_mid_jobs(int jobs) { g_mid_jobs = jobs; }
 template <class K>
 static hipError_t lf_lds(K kernel, size_t bytes)
@@ -484,31 +533,32 @@ hipError_t launch_lf_fwd(int R, const float *in, int64_t in_stride, int64_t in_l
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_lf_mid(bool hprep, int R, c32 *A, c32 *Hs, const int32_t *job_irch, int irch_all, int nframes,
+hipError_t launch_lf_mid(bool hprep, bool ab, int R, c32 *A, c32 *Hs, const int32_t *job_irch, int irch_all, int nframes,
                          int frames_run, int njobs, const c32 *tab, const c32 *tab_row, hipStream_t s)
 {
     if (frames_run <= 0) return hipSuccess;
     if (!hprep && njobs >= 16 && g_mid_jobs) {
-        const size_t ldsj = sizeof(c32) * (2 * LF_C + tw_table_points<LF_C>());
-        const int JB = g_mid_jobs;
-#define WP_MID_JOBS(N)                                                                                                        \
-    hipLaunchKernelGGL((k_lf_mid_jobs<N>), dim3((njobs + N - 1) / N, R / 2, frames_run), dim3(256), ldsj, s, A, Hs, job_irch, \
-                       irch_all, R, nframes, njobs, tab, tab_row)
-        if (JB == 4)
-            WP_MID_JOBS(4);
-        else if (JB == 16)
-            WP_MID_JOBS(16);
+        constexpr int JB = 8;
+        const size_t ldsj = sizeof(c32) * (2 * lds_points32<LF_C>() + tw_table_points<LF_C>());
+        const dim3 grid((njobs + JB - 1) / JB, R / 2, frames_run);
+        if (ab)
+            hipLaunchKernelGGL((k_lf_mid_jobs<JB, true>), grid, dim3(256), ldsj, s, A, Hs, job_irch, irch_all, R, nframes, njobs, tab, tab_row);
         else
-            WP_MID_JOBS(8);
-#undef WP_MID_JOBS
+            hipLaunchKernelGGL((k_lf_mid_jobs<JB, false>), grid, dim3(256), ldsj, s, A, Hs, job_irch, irch_all, R, nframes, njobs, tab, tab_row);
         return hipGetLastError();
     }
     const size_t lds = sizeof(c32) * 2 * LF_C;
     const dim3 grid(njobs, R / 2, frames_run), block(256);
-    if (hprep)
-        hipLaunchKernelGGL((k_lf_mid<true>), grid, block, lds, s, A, Hs, job_irch, irch_all, R, nframes, tab, tab_row);
+#define WP_MID(H, B) hipLaunchKernelGGL((k_lf_mid<H, B>), grid, block, lds, s, A, Hs, job_irch, irch_all, R, nframes, tab, tab_row)
+    if (hprep && ab)
+        WP_MID(true, true);
+    else if (hprep)
+        WP_MID(true, false);
+    else if (ab)
+        WP_MID(false, true);
     else
-        hipLaunchKernelGGL((k_lf_mid<false>), grid, block, lds, s, A, Hs, job_irch, irch_all, R, nframes, tab, tab_row);
+        WP_MID(false, false);
+#undef WP_MID
     return hipGetLastError();
 }
 

@@ -317,7 +317,8 @@ double wp_bpm_from_beat_rate(double sample_rate, int64_t beat_rate);
 #define WP_TUNE_MAC_FORM 2  /* 1 streaming delay-line kernel, 2 small-batch gather kernel */
 #define WP_TUNE_CONV_FORM 5 /* convolution form of IR handles created afterwards: 1 partitioned, 2 long-frame where the sizes allow */
 #define WP_TUNE_LF_RUNS 6   /* long-frame form: at most this many runs of equal frames per result (1..3; 1 = one frame size) */
-#define WP_TUNE_MID_FORM 7  /* long-frame row pass, jobs a workgroup walks: 1, 4, 8 (the default for batches) or 16; takes effect at once */
+#define WP_TUNE_MID_FORM 7  /* long-frame row pass: 1 one job per workgroup, 2 eight (the default for batches; takes effect at once) */
+#define WP_TUNE_LF_SPECTRA 8 /* long-frame kernel spectra of IR handles created afterwards: 1 plain spectra, 2 product coefficients when the jobs share few kernels (default) */
 #define WP_TUNE_FWD_FORM 4  /* forward transform: 1 one segment per workgroup, 2 two (the default; takes effect at once) */
 #define WP_TUNE_POOL_MB 3   /* cap of the wp_buf recycling pool in MiB (default 2048; 0 disables it) */
 int wp_tune(int what, int64_t value);

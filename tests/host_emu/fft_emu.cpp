@@ -138,9 +138,49 @@ double test_odft()
     return maxerr;
 }
 
+// lds_pad32 layout: the padded position of every exchanged element equals the butterfly's padded base plus the
+// compile-time constant the kernels use (pad32_store_k / pad32_load_k), for every thread of the plan; and no two
+// elements of a row share a position
+template <int B>
+static int test_pad32()
+{
+    constexpr int NT = B / FftPlan<B>::PT, NSTAGE = FftPlan<B>::NSTAGE;
+    int bad = 0;
+    c32 v[FftPlan<B>::PT] = {};
+    for (int tid = 0; tid < NT; tid++) {
+        static_for<0, NSTAGE>([&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+            constexpr int NS = plan_ns<B>(S), STRIDE = B / FftPlan<B>::radix(S);
+            stage_store<B, S, false>(tid, v, [&](int i, c32, auto t, auto) {
+                if (lds_pad32(i) != lds_pad32(i - int(t) * NS) + pad32_store_k<NS>(int(t))) bad++;
+            });
+            stage_load_t<B, S>(tid, v, [&](int j, auto t, auto) {
+                if (lds_pad32(j + int(t) * STRIDE) != lds_pad32(j) + pad32_load_k<STRIDE>(int(t))) bad++;
+                return c32{0.f, 0.f};
+            });
+        });
+    }
+    std::vector<int> seen(lds_points32<B>(), 0);
+    for (int i = 0; i < B; i++) {
+        if (lds_pad32(i) < 0 || lds_pad32(i) >= lds_points32<B>() || seen[lds_pad32(i)]++) bad++;
+    }
+    // the row pass's bin pairs: k2 = tid + 256*q and C-1-k2, 264 padded positions per q
+    for (int tid = 0; tid < 256 && B == 2048; tid++)
+        for (int q = 0; q < B / 256; q++) {
+            if (lds_pad32(tid + 256 * q) != lds_pad32(tid) + 264 * q) bad++;
+            if (lds_pad32(B - 1 - tid - 256 * q) != lds_pad32(B - 1 - tid) - 264 * q) bad++;
+        }
+    return bad;
+}
+
 int main()
 {
     int bad = 0;
+    {
+        const int b = test_pad32<2048>();
+        printf("%-28s mismatches %d %s\n", "pad32 layout 2048", b, b == 0 ? "ok" : "FAIL");
+        bad += b;
+    }
 #define CHECK(name, val, tol)                                  \
     do {                                                       \
         double e = (val);                                      \
