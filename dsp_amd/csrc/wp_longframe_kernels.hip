@@ -247,6 +247,11 @@ __global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const 
 
     c32 v[16], vn[16];
     fetch(job0, vn);
+    // The first job's rows are waited for here, ahead of the loop: with loads still in flight on entry and
+    // only stores on the way round, the wait the compiler places at the loop's head would have to cover
+    // both, i.e. drain every pass's stores before the next pass starts.
+#pragma unroll
+    for (int t = 0; t < 16; t++) asm volatile("" ::"v"(vn[t].x), "v"(vn[t].y));
 #pragma unroll 1
     for (int job = job0; job < jend; job++) {
 #pragma unroll
@@ -260,6 +265,16 @@ __global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const 
         // once, ahead of the loop, and held in some 150 registers across it
         int ff = ft, tl = tid;
         asm volatile("" : "+v"(ff), "+v"(tl));
+#if defined(WP_MID_ABLATE)  // measurement builds only: 1 = rows copied through registers, 2 = forward transform only
+        if (WP_MID_ABLATE == 2) middle_stages32<C, false>(ff, v, ldsrow, tw);
+        stage_store<C, LAST, false>(ff, v, [&](int i, c32 val, auto t, auto) {
+            int64_t at = ((int64_t)job * nframes + frame) * Nc + int(t) * NSL;
+            asm volatile("" : "+s"(at));
+            st_nt(Arow + (i - int(t) * NSL) + at, val);
+        });
+        __syncthreads();
+        continue;
+#endif
         middle_stages32<C, false>(ff, v, ldsrow, tw);
         __syncthreads();  // every lane has taken its last-stage inputs out of LDS
         stage_store<C, LAST, false>(ff, v, [&](int i, c32 val, auto t, auto) {
