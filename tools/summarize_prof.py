@@ -93,7 +93,7 @@ for k in acc:
     if base == "k_lf_inv":  # k_lf_inv<R, COLS, MIX, WRITE>
         flags = k.replace(" ", "").split(",")[2:4]
         base = "k_lf_inv" + ("_mix" if flags and flags[0].startswith("true") else "") + ("_w" if len(flags) > 1 and flags[0].startswith("true") and flags[1].startswith("true") else "")
-    if base == "k_lf_mid" and "true" in k:
+    if k.startswith("k_lf_mid<true"):
         continue  # the one-off kernel-spectrum launch
     if base in ("k_lf_fwd", "k_lf_mid", "k_lf_inv", "k_lf_inv_mix", "k_lf_inv_mix_w", "k_fft_fwd", "k_mac", "k_fft_inv", "k_fft_inv_mix", "k_fft_inv_mix_w", "k_mix") and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
         # the PMC passes run ONE bench step: every launch of the family added up (the runs of frames of the long-frame
