@@ -268,7 +268,11 @@ __global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const 
 #if defined(WP_MID_ABLATE)  // measurement builds only: 1 = rows copied through registers, 2 = forward transform only
         if (WP_MID_ABLATE == 2) middle_stages32<C, false>(ff, v, ldsrow, tw);
         stage_store<C, LAST, false>(ff, v, [&](int i, c32 val, auto t, auto) {
+#if defined(WP_MID_ABLATE_SHIFT)  // results written to another job's rows: the stream is no longer in place (timing only)
+            int64_t at = ((int64_t)((job + njobs / 2) % njobs) * nframes + frame) * Nc + int(t) * NSL;
+#else
             int64_t at = ((int64_t)job * nframes + frame) * Nc + int(t) * NSL;
+#endif
             asm volatile("" : "+s"(at));
             st_nt(Arow + (i - int(t) * NSL) + at, val);
         });

@@ -525,6 +525,42 @@ def test_long_frame_form_vs_oracle(torch, oracle, L, M, tracks, cap, runs):
     assert torch.equal(b4.view(torch.int32), b6.view(torch.int32)) and torch.equal(b5.view(torch.int32), b6.view(torch.int32))
 
 
+@pytest.mark.parametrize("own_ir", [False, True])
+def test_long_frame_batch_row_pass_vs_oracle(torch, oracle, own_ir):
+    """Batches of 16 jobs or more take the row pass that walks eight jobs per workgroup: 18 jobs (two full
+    groups and a group of two) with a shared stereo impulse response (kernel spectra stored as product
+    coefficients) and with an impulse response per job (plain spectra), every job against the oracle and the
+    batch against one-job calls of the same handle bit for bit."""
+    from dsp_amd import capi, device
+    lib = capi.lib()
+    L, M, njobs = 300000, 3000, 18
+    nir = njobs if own_ir else 2
+    irs = np.stack([oracle.synth_ir(M, 700 + c) for c in range(nir)])
+    capi.check(lib.wp_tune(5, 2), "wp_tune")  # long-frame form
+    try:
+        ir = device.DeviceIR(torch.from_numpy(irs).cuda(), L)
+    finally:
+        lib.wp_tune(5, 0)
+    assert ir.info(10) >= 1
+    job_ch = list(range(njobs)) if own_ir else [j % 2 for j in range(njobs)]
+    conv = device.BatchedConvolver(ir, job_ch)
+    assert lib.wp_conv_info(conv.handle, 6) == 1
+    x = np.stack([oracle.synth_noise(L, 1200 + j) for j in range(njobs)])
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty((njobs, L + M), dtype=torch.float32, device="cuda")
+    conv.run(xd, out)
+    got = out.cpu().numpy()
+    kern = [oracle.fft_process_kernel(L, irs[c]) for c in range(nir)]
+    for j in range(njobs):
+        want = oracle.fft_convolution(L, kern[job_ch[j]], M)(x[j])
+        assert float(np.abs(got[j].astype(np.float64) - want).max()) <= TOL, j
+    for j in (0, 9, 17):  # the one-job plan runs the row pass with one job per workgroup: same arithmetic
+        one = device.BatchedConvolver(ir, [job_ch[j]])
+        o1 = torch.empty((1, L + M), dtype=torch.float32, device="cuda")
+        one.run(xd[j:j + 1], o1)
+        assert torch.equal(o1[0].view(torch.int32), out[j].view(torch.int32)), j
+
+
 def test_mix_4096_aliased_stems_exact(torch):
     """The master reduce at its full source count: 4096 stereo sources (all views of one
     60 s stem, so the test holds 46 MB instead of 94 GB) with vol = 1/4096.  Samples with 11
