@@ -103,9 +103,10 @@ __global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_fwd(const float *__restr
     c32 pw[R1], wj[NB];
     lf_powers<R1>(lf_w(tab, 16 * c), pw);
     static_for<0, NB>([&](auto u) { wj[u] = lf_w(tab, c * (j + int(u) * NTF)); });
-    c32 *a = A + ((int64_t)job * nframes + frame) * Nc + c;
+    c32 *a = A + ((int64_t)job * nframes + frame) * Nc + lf_col_off(c);
     stage_store<R, 1, false>(j, v, [&](int k1, c32 val, auto t, auto u) {
-        st_nt(a + (int64_t)k1 * C, cmul(val, cmul(wj[u], pw[t])));
+        // k1 = j' + 16*t with j' < 16: the row offset is a constant of t plus 64*j'
+        st_nt(a + (k1 - 16 * int(t)) * LF_CC + lf_row_off(16 * int(t)), cmul(val, cmul(wj[u], pw[t])));
     });
 }
 
@@ -146,15 +147,16 @@ __global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__rest
     const int job = blockIdx.x, k1 = blockIdx.y, frame = blockIdx.z;  // jobs fastest: neighbours share the kernel spectrum rows
     const int64_t Nc = (int64_t)R * C;
     const int row = half ? R - 1 - k1 : k1;
-    c32 *rowp = A + (((int64_t)job * nframes + frame) * R + row) * C;
+    c32 *rowp = A + ((int64_t)job * nframes + frame) * R * C + lf_row_off(row);  // point n of the row: rowp + lf_col_off(n)
     c32 *ldsrow = lds + half * C;
     const TwTables<C> tw = load_tables<C, false>(tab_row, tws, ft);
 
     c32 v[16];
-    stage_load<C, 0>(ft, v, [&](int n) { return ld_nt(rowp + n); });
+    stage_load<C, 0>(ft, v, [&](int n) { return ld_nt(rowp + lf_col_off(n)); });
     const int irch = HPREP ? job : (job_irch ? job_irch[job] : irch_all);
-    c32 *ha = Hs + ((int64_t)irch * R + k1) * C * (AB ? 2 : 1);
-    c32 *hb = Hs + ((int64_t)irch * R + (R - 1 - k1)) * C * (AB ? 2 : 1);
+    // plain spectra lie like a frame of A (a job that reads its own from HBM streams them the same way)
+    c32 *ha = AB ? Hs + ((int64_t)irch * R + k1) * C * 2 : Hs + (int64_t)irch * R * C + lf_row_off(k1);
+    c32 *hb = AB ? Hs + ((int64_t)irch * R + (R - 1 - k1)) * C * 2 : Hs + (int64_t)irch * R * C + lf_row_off(R - 1 - k1);
     middle_stages<C, false>(ft, v, ldsrow, tw);
     __syncthreads();  // every lane has taken its last-stage inputs out of LDS
     stage_store<C, FftPlan<C>::NSTAGE - 1, false>(ft, v, [&](int i, c32 val, int, int) { ldsrow[lds_pad(i)] = val; });
@@ -187,11 +189,11 @@ __global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__rest
                     reinterpret_cast<c32x2 *>(ha)[k2] = pa;
                     reinterpret_cast<c32x2 *>(hb)[p2] = pb;
                 } else {
-                    ha[k2] = a;
-                    hb[p2] = b;
+                    ha[lf_col_off(k2)] = a;
+                    hb[lf_col_off(p2)] = b;
                 }
             } else {
-                const c32 ya = cmul(xa, ha[k2]), yb = cmul(xb, hb[p2]);
+                const c32 ya = cmul(xa, ha[lf_col_off(k2)]), yb = cmul(xb, hb[lf_col_off(p2)]);
                 lds[lds_pad(k2)] = bin_unsplit(ya, yb, wk);
                 lds[C + lds_pad(p2)] = bin_unsplit(yb, ya, wp);
             }
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__rest
     int fi = ft;  // hidden from the optimiser, which would otherwise keep the forward transform's twiddle powers alive for the inverse (119 instead of 76 registers)
     asm volatile("" : "+v"(fi));
     middle_stages<C, true>(fi, v, ldsrow, tw);
-    stage_store<C, FftPlan<C>::NSTAGE - 1, true>(fi, v, [&](int i, c32 val, int, int) { st_nt(rowp + i, val); });
+    stage_store<C, FftPlan<C>::NSTAGE - 1, true>(fi, v, [&](int i, c32 val, int, int) { st_nt(rowp + lf_col_off(i), val); });
 }
 
 // The row pass for batches: a workgroup walks JB consecutive jobs of its row pair with the next job's
@@ -233,12 +235,12 @@ __global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const 
     const TwTables<C> tw = load_tables<C, true>(tab_row, tws, tid);  // first used behind the first exchange's barrier
     // a row access = a base that is the same in every lane (job, frame, point group; kept in scalar registers by
     // an empty asm, or the optimiser folds it into sixteen per-lane 64-bit offsets) + one per-lane offset
-    c32 *__restrict__ Arow = A + (int64_t)row * C;
+    c32 *__restrict__ Arow = A + lf_row_off(row);
     auto fetch = [&](int job, c32 *v) {
-        static_for<0, 16>([&](auto t) {
-            int64_t at = ((int64_t)job * nframes + frame) * Nc + int(t) * (C / 16);
+        static_for<0, 16>([&](auto t) {  // point ft + 128*t: chunk (ft >> 6) + 2*t, column ft & 63 of it
+            int64_t at = ((int64_t)job * nframes + frame) * Nc + lf_col_off(int(t) * (C / 16));
             asm volatile("" : "+s"(at));
-            v[t] = ld_nt(Arow + ft + at);
+            v[t] = ld_nt(Arow + lf_col_off(ft) + at);
         });
     };
     const c32 wa = tab[LF_WA + k1];
@@ -258,8 +260,8 @@ __global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const 
         for (int i = 0; i < 16; i++) v[i] = vn[i];
         if (job + 1 < jend) fetch(job + 1, vn);
         const int irch = job_irch ? job_irch[job] : irch_all;
-        const c32 *ha = Hs + ((int64_t)irch * R + k1) * C * (AB ? 2 : 1);
-        const c32 *hb = Hs + ((int64_t)irch * R + (R - 1 - k1)) * C * (AB ? 2 : 1);
+        const c32 *ha = AB ? Hs + ((int64_t)irch * R + k1) * C * 2 : Hs + (int64_t)irch * R * C + lf_row_off(k1);
+        const c32 *hb = AB ? Hs + ((int64_t)irch * R + (R - 1 - k1)) * C * 2 : Hs + (int64_t)irch * R * C + lf_row_off(R - 1 - k1);
         // the thread indices are hidden from the optimiser once per job (and once more between the two
         // transforms): every LDS address and twiddle power derived from them would otherwise be computed
         // once, ahead of the loop, and held in some 150 registers across it
@@ -269,12 +271,12 @@ __global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const 
         if (WP_MID_ABLATE == 2) middle_stages32<C, false>(ff, v, ldsrow, tw);
         stage_store<C, LAST, false>(ff, v, [&](int i, c32 val, auto t, auto) {
 #if defined(WP_MID_ABLATE_SHIFT)  // results written to another job's rows: the stream is no longer in place (timing only)
-            int64_t at = ((int64_t)((job + njobs / 2) % njobs) * nframes + frame) * Nc + int(t) * NSL;
+            int64_t at = ((int64_t)((job + njobs / 2) % njobs) * nframes + frame) * Nc + lf_col_off(int(t) * NSL);
 #else
-            int64_t at = ((int64_t)job * nframes + frame) * Nc + int(t) * NSL;
+            int64_t at = ((int64_t)job * nframes + frame) * Nc + lf_col_off(int(t) * NSL);
 #endif
             asm volatile("" : "+s"(at));
-            st_nt(Arow + (i - int(t) * NSL) + at, val);
+            st_nt(Arow + lf_col_off(i - int(t) * NSL) + at, val);
         });
         __syncthreads();
         continue;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const 
             } else {
                 const c32 wp = c32{-wk[q].x, wk[q].y};  // the partner's factor: -conj(wk)
                 const c32 xa = bin_split(za, zb, wk[q]), xb = bin_split(zb, za, wp);
-                const c32 ya = cmul(xa, ha[k2]), yb = cmul(xb, hb[p2]);
+                const c32 ya = cmul(xa, ha[lf_col_off(k2)]), yb = cmul(xb, hb[lf_col_off(p2)]);
                 za_s = bin_unsplit(ya, yb, wk[q]);
                 zb_s = bin_unsplit(yb, ya, wp);
             }
@@ -310,9 +312,9 @@ __global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const 
         __syncthreads();  // all stage-0 inputs are in registers before the first exchange overwrites the row
         middle_stages32<C, true>(fi, v, ldsrow, tw);
         stage_store<C, LAST, true>(fi, v, [&](int i, c32 val, auto t, auto) {
-            int64_t at = ((int64_t)job * nframes + frame) * Nc + int(t) * NSL;
+            int64_t at = ((int64_t)job * nframes + frame) * Nc + lf_col_off(int(t) * NSL);
             asm volatile("" : "+s"(at));
-            st_nt(Arow + (i - int(t) * NSL) + at, val);
+            st_nt(Arow + lf_col_off(i - int(t) * NSL) + at, val);
         });
         __syncthreads();  // the next job's first exchange writes the rows this one's last exchange read
     }
@@ -358,10 +360,11 @@ __global__ __launch_bounds__(COLS *R / 16) void k_lf_inv(const c32 *__restrict__
     // A tile access = a base that is the same in every lane (job, frame, row group: scalar registers, passed
     // through an empty asm so that the optimiser does not fold it into sixteen per-lane 64-bit offsets that
     // would live across the source loop) + one per-lane offset.
-    const c32 *__restrict__ At = A + (j * C + c);
+    static_assert(LF_RB % NTF == 0, "rows j + t*NTF, j < NTF: the row offset splits into a constant of t and LF_CC*j");
+    const c32 *__restrict__ At = A + (j * LF_CC + lf_col_off(c));
     auto fetch = [&](int job, c32 *v) {
         static_for<0, PT>([&](auto t) {
-            int64_t at = ((int64_t)job * nframes + frame) * Nc + (int64_t)(int(t) * NTF) * C;
+            int64_t at = ((int64_t)job * nframes + frame) * Nc + lf_row_off(int(t) * NTF);
             asm volatile("" : "+s"(at));
             v[t] = ld_nt(At + at);
         });
