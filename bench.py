@@ -60,6 +60,7 @@ def parse():
                     "for rehearsing the multi-rank flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--lib", default=None, help="a variant build of libwpdsp.so to measure instead of the in-tree one")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
                     help="wp_tune(knob, value) before the plans are made (measurements of the library's alternatives)")
     ap.add_argument("--cpu-tracks", type=int, default=20, help="stereo tracks in the bounded CPU sample")
@@ -225,6 +226,8 @@ def main():
     import torch
     import torch.distributed as dist
     from dsp_amd import capi
+    if a.lib:
+        capi.LIB_PATH = os.path.abspath(a.lib)
     from dsp_amd import device as dev
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
