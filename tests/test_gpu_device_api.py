@@ -561,6 +561,58 @@ def test_long_frame_batch_row_pass_vs_oracle(torch, oracle, own_ir):
         assert torch.equal(o1[0].view(torch.int32), out[j].view(torch.int32)), j
 
 
+def test_long_frame_edge_cases(torch, oracle):
+    """Long-frame plans at the edges the partitioned form is tested at: no input at all (zeros), a carried tail
+    added to the head of the results (lib/impulse-reverb.js:14-16), a bus shorter than the first run of frames
+    (later frames are skipped by the bus-only entry point, not by the one that writes results), and a bus of
+    length zero."""
+    from dsp_amd import capi, device
+    lib = capi.lib()
+    L, M, njobs = 700000, 4000, 2
+    irs = np.stack([oracle.synth_ir(M, 810 + c) for c in range(2)])
+    capi.check(lib.wp_tune(5, 2), "wp_tune")
+    try:
+        ir = device.DeviceIR(torch.from_numpy(irs).cuda(), L)
+    finally:
+        lib.wp_tune(5, 0)
+    conv = device.BatchedConvolver(ir, [0, 1])
+    assert lib.wp_conv_info(conv.handle, 6) == 1
+    x = np.stack([oracle.synth_noise(L, 910 + j) for j in range(njobs)])
+    xd = torch.from_numpy(x).cuda()
+    want = [oracle.fft_convolution(L, oracle.fft_process_kernel(L, irs[j]), M)(x[j]) for j in range(njobs)]
+    out = torch.full((njobs, L + M), 5.0, dtype=torch.float32, device="cuda")
+    conv.run(xd, out, in_len=0)
+    assert float(out.abs().max()) == 0.0
+    prev = torch.from_numpy(np.stack([oracle.synth_noise(M, 930 + j) for j in range(njobs)])).cuda()
+    conv.run(xd, out, prev=prev, prev_len=M - 7)
+    got = out.cpu().numpy()
+    for j in range(njobs):
+        w = want[j].astype(np.float64).copy()
+        w[:M - 7] = (want[j][:M - 7].astype(np.float32) + prev[j, :M - 7].cpu().numpy()).astype(np.float64)
+        assert float(np.abs(got[j].astype(np.float64) - w).max()) <= 2 * TOL, j
+    hop0 = lib.wp_conv_info(conv.handle, 18)
+    for tl in (hop0 // 3, 0):
+        bus = torch.full((2, max(tl, 1)), 0.25, dtype=torch.float32, device="cuda")
+        bus2 = bus.clone()
+        out2 = torch.full((njobs, L + M), 9.0, dtype=torch.float32, device="cuda")
+        tp = (C.c_void_p * 2)(bus[0].data_ptr(), bus[1].data_ptr())
+        tp2 = (C.c_void_p * 2)(bus2[0].data_ptr(), bus2[1].data_ptr())
+        vol = (C.c_double * 1)(0.5)
+        capi.check(lib.wp_conv_mix_run_dev(conv.handle, C.c_void_p(xd.data_ptr()), xd.stride(0), L, tp, tl, vol, None), "wp_conv_mix_run_dev")
+        capi.check(lib.wp_conv_run_mix_dev(conv.handle, C.c_void_p(xd.data_ptr()), xd.stride(0), L, C.c_void_p(out2.data_ptr()),
+                                           out2.stride(0), tp2, tl, vol, None), "wp_conv_run_mix_dev")
+        torch.cuda.synchronize()
+        assert torch.equal(bus.view(torch.int32), bus2.view(torch.int32))
+        g2 = out2.cpu().numpy()
+        for j in range(njobs):
+            assert float(np.abs(g2[j].astype(np.float64) - want[j]).max()) <= TOL, (tl, j)
+        if tl:
+            wb = np.float32(0.25) + (want[0][:tl].astype(np.float32) * np.float32(0.5))
+            assert float(np.abs(bus[0, :tl].cpu().numpy().astype(np.float64) - wb.astype(np.float64)).max()) <= TOL
+        else:
+            assert float((bus - 0.25).abs().max()) == 0.0
+
+
 def test_mix_4096_aliased_stems_exact(torch):
     """The master reduce at its full source count: 4096 stereo sources (all views of one
     60 s stem, so the test holds 46 MB instead of 94 GB) with vol = 1/4096.  Samples with 11
