@@ -5,21 +5,26 @@
 // sample twice (Z and W): 40 bytes per output sample.  For inputs much longer than the impulse
 // response the same linear convolution is cheaper as overlap-save with frames of N2 = 2*Nc real
 // samples that each hold the WHOLE impulse response: a frame advances by hop = N2 - Mpad samples
-// (Mpad >= M-1) and costs 20 bytes per frame sample plus 4 per output sample, about 29 bytes per
-// output sample at N2 = 2^19, M = 96 000, and there is no multiply-accumulate over partitions.
+// (Mpad >= M-1) and costs 20 bytes per frame sample plus 4 per output sample (26 bytes per output
+// sample for a 60 s track and a 2 s response covered by three frames of 2^20 samples and one of
+// 2^18), and there is no multiply-accumulate over partitions.  A result is covered by up to three
+// runs of equal frames (wp_api.hip: choose_lf); every kernel here handles one run per launch.
 //
 // A frame is packed as Nc complex points z[m] = x[2m] + i x[2m+1], pre-twisted by exp(-i*pi*m/Nc)
 // (odd-frequency transform, wp_fft.h) and transformed by a four-step FFT, Nc = R * C, m = r*C + c:
 //   k_lf_fwd   R-point transforms down the columns (tiles of 32 columns x R rows, 256-byte runs),
 //              times exp(-2*pi*i*c*k1/Nc)                              -> A[k1][c]
-//   k_lf_mid   per row pair (k1, R-1-k1): C-point transform along the row gives bins k1 + R*k2;
+//   k_lf_mid, k_lf_mid_jobs
+//              per row pair (k1, R-1-k1): C-point transform along the row gives bins k1 + R*k2;
 //              the partner bin Nc-1-k sits in the other row at C-1-k2, so the real/packed split,
 //              the product with the kernel spectrum, the unsplit and the inverse C-point
-//              transform all happen in one workgroup, in place
+//              transform all happen in one workgroup, in place (k_lf_mid_jobs: for eight jobs in
+//              turn, the next job's rows in flight)
 //   k_lf_inv   conj twiddle, inverse R-point transforms down the columns, post-twist, the
 //              frame's last hop samples written out; with MIX the workgroup walks the sources
 //              in order and folds the samples into the master bus (src/mix-buffers.js:49-52)
 //              exactly as k_fft_inv_mix does.
+// A[k1][c] is stored in blocks of 32 rows x chunks of 64 columns (wp_internal.h: lf_row_off, lf_col_off).
 // All three are HBM-bound streaming kernels; nothing here is a dense contraction (no MFMA).
 #include <hip/hip_runtime.h>
 
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__rest
     constexpr int C = LF_C, NT = C / 16;
     extern __shared__ __align__(16) unsigned char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
-    c32 *tws = lds + 2 * C;  // unused: the row transform reads its tables from global memory
+    c32 *tws = lds + 2 * C;  // not filled: this kernel's row transforms read their tables from global memory
     const int tid = threadIdx.x, half = tid >> 7, ft = tid & (NT - 1);
     const int job = blockIdx.x, k1 = blockIdx.y, frame = blockIdx.z;  // jobs fastest: neighbours share the kernel spectrum rows
     const int64_t Nc = (int64_t)R * C;
