@@ -15,7 +15,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // (WP_PLAIN_SPECTRA builds them as plain accesses: an experiment switch for cache-resident chunked runs)
 __device__ __forceinline__ c32 ld_nt(const c32 *p)
 {
-#ifdef WP_PLAIN_SPECTRA
+#if defined(WP_PLAIN_SPECTRA) || defined(WP_PLAIN_SPECTRA_LD)
     return *p;
 #else
     const v2f t = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
@@ -24,7 +24,7 @@ __device__ __forceinline__ c32 ld_nt(const c32 *p)
 }
 __device__ __forceinline__ void st_nt(c32 *p, c32 v)
 {
-#ifdef WP_PLAIN_SPECTRA
+#if defined(WP_PLAIN_SPECTRA) || defined(WP_PLAIN_SPECTRA_ST)
     *p = v;
 #else
     v2f t;
