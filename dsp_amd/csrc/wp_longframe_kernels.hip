@@ -470,11 +470,14 @@ __global__ __launch_bounds__(COLS *R / 16) void k_lf_inv(const c32 *__restrict__
             for (int i = 0; i < PT; i++) v[i] = vn[i];
             fetch(2 * (s + 1 < nsrc ? s + 1 : nsrc - 1) + ch, vn);  // clamped: always a valid tile
             const double g = vol[s];
+#if !defined(WP_INV_ABLATE)  // measurement builds: the tile goes out as it came in (same loads, stores and fold)
             static_for<0, PT>([&](auto t) { v[t] = cmul(v[t], tinL[int(t) * NT]); });
             stage_compute<R, 0, true>(j, v, tw);
             stage_store<R, 0, true>(j, v, [&](int i, c32 val, int, int) { lds[i * COLS + col] = val; });
             __syncthreads();
             stage_load<R, 1>(j, v, [&](int i) { return lds[i * COLS + col]; });
+#endif
+#if !defined(WP_INV_ABLATE)
             {
                 c32 wl[NB];  // hidden from the optimiser: the powers derived from them would otherwise live across the loop
                 static_for<0, NB>([&](auto u) {
@@ -483,6 +486,7 @@ __global__ __launch_bounds__(COLS *R / 16) void k_lf_inv(const c32 *__restrict__
                 });
                 stage_compute_with<R, 1, true>(v, wl);
             }
+#endif
             float *yb = WRITE ? out + (int64_t)(2 * s + ch) * out_stride + first : nullptr;
             const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yb, 0, nrec, 0x00020000);
             const float g32 = (float)g;
