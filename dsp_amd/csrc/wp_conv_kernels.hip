@@ -533,7 +533,7 @@ static hipError_t launch_fwd_t(bool irmode, const float *in, int64_t in_stride, 
     const dim3 grid(nblocks, njobs), block(B / FftPlan<B>::PT);
     if (irmode)
         hipLaunchKernelGGL((k_fft_fwd<B, true>), grid, block, (fft_lds_bytes<B, false>()), s, in, in_stride, in_len, Z, T, tables);
-    else if (g_fwd_pair && nblocks > 1)
+    else if (g_fwd_pair && nblocks > 1 && (int64_t)nblocks * njobs >= 4096)  // (a launch that does not fill the chip is over sooner with a workgroup per segment; same bits)
         hipLaunchKernelGGL((k_fft_fwd_pair<B>), dim3((nblocks + 1) / 2, njobs), block, (fft_lds_bytes<B, false>()), s, in,
                            in_stride, in_len, Z, T, nblocks, tables);
     else
