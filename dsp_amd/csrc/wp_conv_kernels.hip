@@ -240,16 +240,23 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv_mix(const c32 *_
         const c32 *w = W + ((int64_t)(2 * (src < nsrc ? src : nsrc - 1) + ch) * T + t) * B;
         stage_load<B, 0>(tid, v, [&](int n) { return w[n]; });
     };
-    auto transform_fold = [&](c32 *v, int src, double g) {
+    // the post-twist factors of this thread's butterflies (index i mod NS: the same for every output of a
+    // butterfly), looked up once: a table load inside the source loop would be younger than the next
+    // source's spectrum in flight, and its wait would wait for that too
+    c32 th[PT / R];
+    static_for<0, PT / R>([&](auto u) { th[u] = thalf[(tid + int(u) * NT) & (NS - 1)]; });
+    // FULLW: every source's block of samples lies inside its result and is 8-byte aligned (the same for all
+    // sources when the rows are an even number of floats apart): the stores are then unconditional, so the
+    // wait for the next source's spectrum can count them instead of waiting for them as well
+    auto transform_fold = [&](c32 *v, int src, double g, auto FULLW) {
         middle_stages<B, true>(tid, v, lds, tw);
         float *y = WRITE ? out + (int64_t)(2 * src + ch) * out_stride : nullptr;
-        const bool fullw = WRITE && (o0 + B <= out_len) && ((reinterpret_cast<uintptr_t>(y + o0) & 7) == 0);
         stage_store<B, LAST, true>(tid, v, [&](int i, c32 val, auto tt, auto u) {
             if constexpr (int(tt) >= R / 2) {
-                val = post_twist<B, int(tt)>(val, thalf[i & (NS - 1)]);
+                val = post_twist<B, int(tt)>(val, th[u]);
                 if constexpr (WRITE) {
                     const int64_t o = o0 + 2 * (int64_t)(i - B / 2);
-                    if (fullw) {
+                    if constexpr (decltype(FULLW)::value) {
                         st_nt(reinterpret_cast<c32 *>(y + o), val);
                     } else {
                         if (o < out_len) y[o] = val.x;
@@ -265,6 +272,8 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv_mix(const c32 *_
         });
         __syncthreads();  // every lane is done reading LDS before the next transform overwrites it
     };
+    const bool fullw_all = WRITE && (o0 + B <= out_len) && (out_stride & 1) == 0 &&
+                           (reinterpret_cast<uintptr_t>(out + (int64_t)ch * out_stride + o0) & 7) == 0;
 
     // two register sets: the next source's spectrum is in flight while this one is transformed
     // (capping the 512-thread plan at 128 VGPRs for a second workgroup per CU measured 2x slower).
@@ -272,24 +281,30 @@ __global__ __launch_bounds__(B / FftPlan<B>::PT) void k_fft_inv_mix(const c32 *_
     // source loop and keeps them in some 90 registers (234 in all, two workgroups per CU);
     // recomputing them per source instead (144 registers, three workgroups per CU) measured 3 %
     // slower: the kernel is not bound by occupancy.
-    if constexpr (PT <= 16) {
-        c32 v[PT], vn[PT];
-        fetch(0, vn);
+    auto run_sources = [&](auto FULLW) {
+        if constexpr (PT <= 16) {
+            c32 v[PT], vn[PT];
+            fetch(0, vn);
 #pragma unroll 1
-        for (int s = 0; s < nsrc; s++) {
+            for (int s = 0; s < nsrc; s++) {
 #pragma unroll
-            for (int i = 0; i < PT; i++) v[i] = vn[i];
-            fetch(s + 1, vn);
-            transform_fold(v, s, vol[s]);
-        }
-    } else {
-        c32 v[PT];
+                for (int i = 0; i < PT; i++) v[i] = vn[i];
+                fetch(s + 1, vn);
+                transform_fold(v, s, vol[s], FULLW);
+            }
+        } else {
+            c32 v[PT];
 #pragma unroll 1
-        for (int s = 0; s < nsrc; s++) {
-            fetch(s, v);
-            transform_fold(v, s, vol[s]);
+            for (int s = 0; s < nsrc; s++) {
+                fetch(s, v);
+                transform_fold(v, s, vol[s], FULLW);
+            }
         }
-    }
+    };
+    if (fullw_all)
+        run_sources(ic<1>{});
+    else
+        run_sources(ic<0>{});
 
     if (folds) each_out([&](auto slot, int64_t o) {
         if (full) {
