@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "wp_fft.h"
+#include "wp_lf_layout.h"  // LF_C and the layout of a frame in the long-frame workspace
 #include "../../include/wpdsp.h"
 
 namespace wp {
@@ -51,21 +52,6 @@ hipError_t launch_big_fft(const float *src, int64_t n_real, int64_t N, int inver
 // A frame of 2*Nc real samples = Nc = R*LF_C complex points; R = 64, 128 or 256.  A job's result is covered by
 // up to LF_MAX_SEG runs of equal frames (largest first); `base` is the first output sample of a run.
 constexpr int LF_MAX_SEG = 3;
-constexpr int LF_C = 2048;
-// Layout of a frame's R x LF_C points in A: blocks of LF_RB = 32 rows x chunks of LF_CC = 64 columns, [row block][chunk][row][64 columns].
-// A row (what the row pass streams) is then 32 pieces of 512 bytes 16 KB apart, which spreads one workgroup's
-// accesses over the memory channels, and the 256-byte runs of the column passes' tiles (32 columns of every row)
-// sit 512 bytes apart instead of 16 KB.
-#ifndef WP_LF_RB
-#define WP_LF_RB 32  // rows per block (a multiple of 16)
-#endif
-#ifndef WP_LF_CC
-#define WP_LF_CC 64  // columns per chunk (divides 128)
-#endif
-constexpr int LF_RB = WP_LF_RB, LF_CC = WP_LF_CC;
-static_assert(LF_RB % 16 == 0 && 128 % LF_CC == 0 && LF_CC >= 32, "frame layout");
-__host__ __device__ constexpr int lf_row_off(int k1) { return (k1 / LF_RB) * (LF_RB * LF_C) + (k1 % LF_RB) * LF_CC; }
-__host__ __device__ constexpr int lf_col_off(int c) { return (c / LF_CC) * (LF_RB * LF_CC) + (c % LF_CC); }
 // device table block of one R (c32 entries):
 //   [LF_T256, +256)  exp(-2*pi*i*a/256)            [LF_ROW, +256)   exp(-i*pi*r/R), r < R
 //   [LF_COL, +2048)  exp(-i*pi*c/Nc), c < LF_C     [LF_FLO, +512)   exp(-2*pi*i*b/Nc), b < 512

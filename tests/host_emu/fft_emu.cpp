@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../dsp_amd/csrc/wp_fft.h"
+#include "../../dsp_amd/csrc/wp_lf_layout.h"
 
 using namespace wp;
 typedef std::complex<double> cd;
@@ -173,9 +174,43 @@ static int test_pad32()
     return bad;
 }
 
+// Layout of a long-frame frame in the workspace (wp_lf_layout.h): every point of an R x LF_C frame has a place of
+// its own inside the frame, and the offsets split the way the kernels use them (a per-lane part + a part that is
+// the same in every lane).
+static int test_lf_layout()
+{
+    int bad = 0;
+    for (int R : {64, 128, 256}) {
+        std::vector<char> seen((size_t)R * LF_C, 0);
+        for (int k1 = 0; k1 < R; k1++)
+            for (int c = 0; c < LF_C; c++) {
+                const int o = lf_row_off(k1) + lf_col_off(c);
+                if (o < 0 || o >= R * LF_C || seen[o]++) bad++;
+            }
+    }
+    for (int t = 0; t < 16; t++) {
+        for (int jp = 0; jp < 16; jp++)  // column passes' outputs and R = 256 inputs: row jp + 16 t
+            if (lf_row_off(jp + 16 * t) != lf_row_off(16 * t) + jp * LF_CC) bad++;
+        for (int ntf : {4, 8, 16})  // inverse column pass inputs: row j + t * R/16
+            for (int j = 0; j < ntf; j++)
+                if (lf_row_off(j + t * ntf) != lf_row_off(t * ntf) + j * LF_CC) bad++;
+        for (int ft = 0; ft < 128; ft++)  // row pass loads: point ft + 128 t
+            if (lf_col_off(ft + 128 * t) != lf_col_off(ft) + lf_col_off(128 * t)) bad++;
+    }
+    for (int t = 0; t < 8; t++)
+        for (int jp = 0; jp < 256; jp++)  // row pass stores: point jp + 256 t
+            if (lf_col_off(jp + 256 * t) != lf_col_off(jp) + lf_col_off(256 * t)) bad++;
+    return bad;
+}
+
 int main()
 {
     int bad = 0;
+    {
+        const int b = test_lf_layout();
+        printf("%-28s mismatches %d %s\n", "long-frame layout", b, b == 0 ? "ok" : "FAIL");
+        bad += b;
+    }
     {
         const int b = test_pad32<2048>();
         printf("%-28s mismatches %d %s\n", "pad32 layout 2048", b, b == 0 ? "ok" : "FAIL");
