@@ -185,10 +185,11 @@ class Workload:
         self.x = self.out = None
 
 
-def verify(w, rank, torch):
+def verify(w, rank, torch, no_oracle=False):
     """One untimed pass of the headline entry point, checked: job 0 of global track 0 against what the
-    reference JavaScript produced for it (committed fixture), and a slice of the rank-local bus against
-    the in-order f64 fold of the written results (src/mix-buffers.js:49-52)."""
+    reference JavaScript produced for it (committed fixture), job 5 and the last job of this rank against
+    the CPU oracle run on the spot, and a slice of the rank-local bus against the in-order f64 fold of the
+    written results (src/mix-buffers.js:49-52)."""
     import numpy as np
     out = w.alloc_out(torch)
     bus = torch.zeros((2, w.F), dtype=torch.float32, device="cuda")
@@ -208,16 +209,37 @@ def verify(w, rank, torch):
             res["job0_ok"] = bool(err <= 1e-5)
         else:
             res["job0_ok"] = None  # non-default sizes: no fixture
+    # further jobs against the oracle computed on the spot (CPU restatement of lib/convolve.js:564-586; checker only):
+    # an odd job inside a group of eight of the row pass, and the last job of the batch
+    if not no_oracle:
+        try:
+            from oracle import oracle as o
+            o.build()
+            worst = 0.0
+            checked = []
+            for j in sorted(set(k for k in (5, w.njobs - 1) if 0 <= k < w.njobs)):
+                track, ch = w.t_lo + j // 2, j % 2
+                h = o.synth_ir(w.M, 500000 + ch if w.config == "c3" else 500000 + 2 * track + ch)
+                want = o.fft_convolution(w.F, o.fft_process_kernel(w.F, h), w.M)(o.synth_noise(w.F, 1000 + 2 * track + ch))
+                got = out[j, :w.out_len].cpu().numpy().astype(np.float64)
+                worst = max(worst, float(np.abs(got - want).max()))
+                checked.append(j)
+            res["oracle_jobs"] = checked
+            res["oracle_jobs_max_abs_err"] = worst
+            res["oracle_jobs_ok"] = bool(worst <= 1e-5)
+        except Exception as e:  # a missing checker is reported, it does not pass
+            res["oracle_jobs_ok"] = None
+            res["oracle_jobs_error"] = repr(e)[:200]
     sl = slice(1234567 % max(1, w.F - 4096), 1234567 % max(1, w.F - 4096) + min(4096, w.F))
-    o = out[:, sl].cpu().numpy()
+    o_ = out[:, sl].cpu().numpy()
     ok = True
     for ch in range(2):
-        acc = np.zeros(o.shape[1], np.float32)
+        acc = np.zeros(o_.shape[1], np.float32)
         for t in range(w.tracks):
-            acc = (acc.astype(np.float64) + o[2 * t + ch].astype(np.float64) * w.vol[t]).astype(np.float32)
+            acc = (acc.astype(np.float64) + o_[2 * t + ch].astype(np.float64) * w.vol[t]).astype(np.float32)
         ok = ok and bool(np.array_equal(acc, bus[ch, sl].cpu().numpy()))
     res["bus_slice_bit_exact"] = ok
-    res["ok"] = bool(ok and res.get("job0_ok") is not False)
+    res["ok"] = bool(ok and res.get("job0_ok") is not False and res.get("oracle_jobs_ok") is not False)
     return res
 
 
@@ -238,7 +260,6 @@ def main():
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     comm = None
-    rccl_group = None
     reduce_kind = "none (one rank)"
     if world > 1:
         if a.reduce == "capi":
@@ -251,28 +272,40 @@ def main():
             os.dup2(2, 1)
             why = ""
             try:
-                comm = dev.Comm(rank, world, dev.gloo_rendezvous(dist))
-            except Exception as e:
-                why = "%s: %s" % (type(e).__name__, e)
-                print("[bench] rank %d: wp_comm_create failed: %s" % (rank, why), file=sys.stderr, flush=True)
+                # agree on readiness BEFORE the collective: wp_comm_create waits for every rank, so a rank that
+                # cannot open RCCL (or has no GPU) must be known to all of them first
+                rc = capi.lib().wp_comm_available()
+                if rc != 0:
+                    why = "wp_comm_available: %s" % capi.lib().wp_last_error().decode()
+                flag = torch.tensor([1.0 if rc == 0 else 0.0], dtype=torch.float64)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if flag.item() == 1.0:
+                    try:
+                        comm = dev.Comm(rank, world, dev.gloo_rendezvous(dist))
+                    except Exception as e:
+                        why = "%s: %s" % (type(e).__name__, e)
+                elif not why:
+                    why = "another rank cannot open RCCL"
             finally:
                 sys.stdout.flush()
                 os.dup2(saved, 1)
                 os.close(saved)
-            # every rank must take the same road: if the communicator is missing anywhere, all ranks fall back to
-            # torch.distributed's own RCCL group for the reduce and the JSON line says so
             flag = torch.tensor([0.0 if comm is None else 1.0], dtype=torch.float64)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if flag.item() == 1.0:
-                reduce_kind = ("wp_bus_reduce: ncclReduce(sum, f32) through the C ABI (%s), side stream, two bus buffers"
-                               % os.path.basename(comm.library))
-            else:
+            if flag.item() != 1.0:
+                # no fallback: the collective the product owns could not be set up, so there is nothing to time
+                print("[bench] rank %d: no communicator (%s)" % (rank, why or "another rank failed"), file=sys.stderr, flush=True)
                 if comm is not None:
                     comm.close()
-                    comm = None
-                rccl_group = dist.new_group(backend="nccl")
-                reduce_kind = ("torch.distributed.reduce (nccl group) -- FALLBACK: wp_comm_create failed on at least one rank%s"
-                               % ((" (%s)" % why[:200]) if why else ""))
+                if rank == 0:
+                    print(json.dumps({"metric": "output Msamples/s (whole node) for stereo IR reverb+mix", "value": None,
+                                      "unit": "Msamples/s", "n_gpus": world, "reduce_fallback": True,
+                                      "error": "wp_comm_create (--reduce capi) failed on at least one rank: %s"
+                                               % (why[:300] or "see the other ranks' stderr")}), flush=True)
+                dist.destroy_process_group()
+                raise SystemExit(3)
+            reduce_kind = ("wp_bus_reduce: ncclReduce(sum, f32) through the C ABI (%s), side stream, two bus buffers"
+                           % os.path.basename(comm.library))
         elif a.backend == "nccl":
             try:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -350,7 +383,7 @@ def main():
             e.record(side)
             reduced[k] = e
         else:
-            dev.reduce_master_bus(bus, dist, dst=0, group=rccl_group)
+            dev.reduce_master_bus(bus, dist, dst=0)
 
     def step(timed, which="main"):
         k = counter[0] % len(buses)
@@ -434,9 +467,20 @@ def main():
                     "ms_per_step": dt5 / a.steps * 1e3, "value": world * njobs * w5.out_len * a.steps / dt5 / 1e6,
                     "unit": "Msamples/s", "partition": int(capi.lib().wp_conv_info(w5.conv.handle, 2))}
         if not a.no_verify:
-            c5_extra["verified"] = verify(w5, rank, torch)
+            v5 = verify(w5, rank, torch)
+            flag = torch.tensor([1.0 if v5["ok"] else 0.0], dtype=torch.float64, device="cpu" if cpu_group_tensor else "cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            v5["all_ranks_ok"] = bool(flag.item() == 1.0)
+            v5["ok"] = v5["ok"] and v5["all_ranks_ok"]
+            c5_extra["verified"] = v5
         w5.close()
 
+    # a failed check (on any rank: `ok` already holds the minimum over ranks) voids the line and the exit status
+    bad = []
+    if verified is not None and not verified["ok"]:
+        bad.append("headline workload")
+    if c5_extra is not None and "verified" in c5_extra and not c5_extra["verified"]["ok"]:
+        bad.append("render_4s_ir")
     if rank == 0:
         K = a.steps
         # samples the timed path produced: every job's L+M result (unfused), or the F frames per job that reach the bus (fused)
@@ -503,6 +547,11 @@ def main():
             res["render_4s_ir"] = c5_extra
         if world == 1 and not a.no_cpu_baseline and a.cpu_tracks > 0:
             res["cpu_baseline"] = cpu_baseline(F, M, a.cpu_tracks)
+        if bad:
+            # a build whose results differ from the reference's has no throughput to report
+            res["measured_value"] = res["value"]
+            res["value"] = None
+            res["error"] = "verification failed: " + "; ".join(bad)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
@@ -510,6 +559,8 @@ def main():
             torch.cuda.synchronize()
             comm.close()
         dist.destroy_process_group()
+    if bad:
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

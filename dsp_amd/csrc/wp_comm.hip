@@ -114,6 +114,15 @@ extern "C" int wp_comm_unique_id(unsigned char *id_out)
     return WP_OK;
 }
 
+extern "C" int wp_comm_available(void)
+{
+    const int n = wp_init();
+    if (n < 0) return n;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return cfail(WP_ERR_HIP, "hipGetDevice failed");
+    return load_rccl();
+}
+
 extern "C" wp_comm *wp_comm_create(const unsigned char *id_bytes, int nranks, int rank)
 {
     if (wp_init() < 0) return nullptr;

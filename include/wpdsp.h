@@ -257,6 +257,11 @@ void wp_comm_destroy(wp_comm *c);
 int64_t wp_comm_info(const wp_comm *c, int which);
 /* Path of the RCCL library in use ("" before the first wp_comm_* call). */
 const char *wp_comm_library(void);
+/* Not collective: WP_OK when this process has a GPU and RCCL can be opened, so that a
+ * host can agree on readiness among its ranks BEFORE any of them enters
+ * wp_comm_create (which waits for all of them); an error code otherwise.  The
+ * reference has no counterpart (its workers share memory, src/mix-worker-thread.js:14-16). */
+int wp_comm_available(void);
 /* recv[i] = sum over ranks of send[i], i < count, on rank `root` (recv_dev may be
  * NULL elsewhere and may equal send_dev); asynchronous on `stream`.  A stereo bus
  * of F frames stored as [2][F] is one call with count = 2*F. */

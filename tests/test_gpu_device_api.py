@@ -526,14 +526,17 @@ def test_long_frame_form_vs_oracle(torch, oracle, L, M, tracks, cap, runs):
 
 
 @pytest.mark.parametrize("own_ir", [False, True])
-def test_long_frame_batch_row_pass_vs_oracle(torch, oracle, own_ir):
+@pytest.mark.parametrize("L,M,frame0", [(300000, 3000, None), (1000000, 96000, 1048576)])
+def test_long_frame_batch_row_pass_vs_oracle(torch, oracle, own_ir, L, M, frame0):
     """Batches of 16 jobs or more take the row pass that walks eight jobs per workgroup: 18 jobs (two full
     groups and a group of two) with a shared stereo impulse response (kernel spectra stored as product
-    coefficients) and with an impulse response per job (plain spectra), every job against the oracle and the
-    batch against one-job calls of the same handle bit for bit."""
+    coefficients) and with an impulse response per job (plain spectra), every job against the oracle, the
+    bus of the one-pass entry point against the oracle's mix of its own results, and the batch against
+    one-job calls of the same handle bit for bit.  The second size is covered by a frame of 2^20 samples
+    (256 rows: the frame size of the 60 s render) and a frame of 2^18."""
     from dsp_amd import capi, device
     lib = capi.lib()
-    L, M, njobs = 300000, 3000, 18
+    njobs = 18
     nir = njobs if own_ir else 2
     irs = np.stack([oracle.synth_ir(M, 700 + c) for c in range(nir)])
     capi.check(lib.wp_tune(5, 2), "wp_tune")  # long-frame form
@@ -545,20 +548,38 @@ def test_long_frame_batch_row_pass_vs_oracle(torch, oracle, own_ir):
     job_ch = list(range(njobs)) if own_ir else [j % 2 for j in range(njobs)]
     conv = device.BatchedConvolver(ir, job_ch)
     assert lib.wp_conv_info(conv.handle, 6) == 1
+    if frame0 is not None:
+        assert lib.wp_conv_info(conv.handle, 16) == frame0, "run 0's frame length"
     x = np.stack([oracle.synth_noise(L, 1200 + j) for j in range(njobs)])
     xd = torch.from_numpy(x).cuda()
     out = torch.empty((njobs, L + M), dtype=torch.float32, device="cuda")
     conv.run(xd, out)
     got = out.cpu().numpy()
     kern = [oracle.fft_process_kernel(L, irs[c]) for c in range(nir)]
+    want = [oracle.fft_convolution(L, kern[job_ch[j]], M)(x[j]) for j in range(njobs)]
+    worst = 0.0
     for j in range(njobs):
-        want = oracle.fft_convolution(L, kern[job_ch[j]], M)(x[j])
-        assert float(np.abs(got[j].astype(np.float64) - want).max()) <= TOL, j
+        err = float(np.abs(got[j].astype(np.float64) - want[j]).max())
+        worst = max(worst, err)
+        assert err <= TOL, (j, err)
     for j in (0, 9, 17):  # the one-job plan runs the row pass with one job per workgroup: same arithmetic
         one = device.BatchedConvolver(ir, [job_ch[j]])
         o1 = torch.empty((1, L + M), dtype=torch.float32, device="cuda")
         one.run(xd[j:j + 1], o1)
         assert torch.equal(o1[0].view(torch.int32), out[j].view(torch.int32)), j
+    # the one-pass entry point (results + bus): same samples as the plain run, bus = the oracle's mixBuffers
+    # of the oracle's results (src/mix-buffers.js:49-52), gains that are not powers of two
+    tracks = njobs // 2
+    vol = [0.9 / (s + 2) for s in range(tracks)]
+    out2 = torch.empty((njobs, L + M), dtype=torch.float32, device="cuda")
+    bus = torch.zeros((2, L), dtype=torch.float32, device="cuda")
+    conv.run_and_mix(xd, out2, [bus[0], bus[1]], vol)
+    torch.cuda.synchronize()
+    assert torch.equal(out2.view(torch.int32), out.view(torch.int32))
+    want_bus = [np.zeros(L, np.float32), np.zeros(L, np.float32)]
+    oracle.mix_buffers(want_bus, *[[[want[2 * s][:L], want[2 * s + 1][:L]], 1, vol[s], 0] for s in range(tracks)])
+    for ch in range(2):
+        assert float(np.abs(bus[ch].cpu().numpy().astype(np.float64) - want_bus[ch]).max()) <= TOL, ch
 
 
 def test_long_frame_edge_cases(torch, oracle):

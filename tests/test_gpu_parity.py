@@ -274,19 +274,33 @@ def test_convolution_properties_full_size(wp, oracle):
     _close(yab, 0.5 * ya.astype(np.float64) + 0.25 * yb, "linearity", tol=2e-6)
 
 
-def test_g7_render_jobs_with_4s_impulse_responses(wp, oracle):
-    """Two channel-jobs of the 2048-track render (L = 2 880 000, M = 192 000: the 8192-point
-    plan, 24 partitions, one impulse response per job) through the batched one-pass entry
-    point, against what the reference JavaScript produced for them."""
+@pytest.mark.parametrize("form", ["long-frame", "partitioned"])
+def test_g7_render_jobs_with_4s_impulse_responses(wp, oracle, form):
+    """Two channel-jobs of the 2048-track render (L = 2 880 000, M = 192 000, one impulse response per
+    job) through the batched one-pass entry point, against what the reference JavaScript produced for
+    them.  Once in the form the library picks for these sizes (long-frame: frames that hold the whole
+    4 s response) and once forced to the partitioned form (the 8192-point plan, 24 partitions)."""
     import torch
-    from dsp_amd import device
+    from dsp_amd import capi, device
+    lib = capi.lib()
     g = load_golden("g7_c5_jobs.json")
     L, M = g["L"], g["M"]
     jobs = g["jobs"]
     irs = torch.from_numpy(np.stack([device.synth_ir(M, j["seed_ir"]) for j in jobs])).cuda()
-    ir = device.DeviceIR(irs, L)
-    assert ir.info(3) == 8192 and ir.info(4) == 24
+    capi.check(lib.wp_tune(5, 0 if form == "long-frame" else 1), "wp_tune")  # WP_TUNE_CONV_FORM
+    try:
+        ir = device.DeviceIR(irs, L)
+    finally:
+        lib.wp_tune(5, 0)
+    assert ir.info(3) == 8192 and ir.info(4) == 24  # the partition plan every handle carries
     conv = device.BatchedConvolver(ir, [0, 1])
+    if form == "long-frame":
+        assert lib.wp_conv_info(conv.handle, 6) == 1
+        frames = [(int(lib.wp_conv_info(conv.handle, 16 + 4 * i)), int(lib.wp_conv_info(conv.handle, 17 + 4 * i)))
+                  for i in range(int(lib.wp_conv_info(conv.handle, 10)))]
+        assert frames[0][0] >= 1048576 and all(f >= 2 * M for f, _ in frames), frames  # every frame holds the whole response
+    else:
+        assert lib.wp_conv_info(conv.handle, 6) == 0 and lib.wp_conv_info(conv.handle, 2) == 8192
     x = torch.empty((2, L), dtype=torch.float32, device="cuda")
     for i, j in enumerate(jobs):
         device.synth_noise(x[i], j["seed_x"])

@@ -108,3 +108,41 @@ def _two_ranks(oracle, use_gpu):
     o.mix_buffers(bus, *srcs)
     err = float(np.abs(got - np.stack(bus)).max())
     assert err <= 1e-5, err
+
+
+def _bench_two_ranks(extra, timeout=420):
+    """bench.py's own multi-rank control flow as a fresh child: two ranks launched the way the driver
+    launches them, both on the one GPU of the test box."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--tracks", "4", "--seconds", "4",
+           "--steps", "2", "--warmup", "1", "--cpu-tracks", "0"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return out, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_flow_with_gloo_reduce():
+    """Track sharding, two bus buffers, barrier + max-over-ranks timing, the verification on every rank
+    (bus slice bit-exact, jobs against the oracle) and the extra 4 s-IR measurement, with the reduce carried
+    by gloo because RCCL refuses two ranks on one device."""
+    out, line = _bench_two_ranks(["--reduce", "torch", "--backend", "gloo"])
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert line is not None and line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    v = line["verified"]
+    assert v["ok"] and v["all_ranks_ok"] and v["bus_slice_bit_exact"] and v["oracle_jobs_ok"], v
+    v5 = line["render_4s_ir"]["verified"]
+    assert v5["ok"] and v5["all_ranks_ok"] and v5["oracle_jobs_ok"], v5
+    assert "reduce_fallback" not in line
+
+
+@pytest.mark.gpu
+def test_bench_refuses_to_time_without_its_own_collective():
+    """--reduce capi with both ranks on one GPU: RCCL rejects the communicator (duplicate device), every rank
+    learns it, and the bench prints a line with value null and exits non-zero instead of timing another
+    library's collective."""
+    out, line = _bench_two_ranks(["--reduce", "capi"], timeout=300)
+    assert out.returncode != 0
+    assert line is not None and line["value"] is None and line["reduce_fallback"] is True, out.stdout[-2000:]
