@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -271,7 +272,8 @@ static int get_tables(int dev, int B, const c32 **out)
     return WP_OK;
 }
 
-static int g_tune_form = 0;  // WP_TUNE_CONV_FORM
+// the wp_tune knobs are atomics: wp_tune on one thread may run beside plan creation on another
+static std::atomic<int> g_tune_form{0};  // WP_TUNE_CONV_FORM
 
 // per-(device, R) tables of the long-frame convolution (layout: wp_internal.h)
 static std::map<std::pair<int, int>, c32 *> g_lf_tables;
@@ -324,15 +326,16 @@ struct LfGeom {
     int64_t mpad = 0;
     int64_t pts = 0;  // complex points per job over all runs
 };
-static int g_tune_lf_runs = 0;  // WP_TUNE_LF_RUNS: 0 = up to LF_MAX_SEG runs of frames, n = at most n
-static int g_tune_lf_ab = 0;    // WP_TUNE_LF_SPECTRA: 1 = plain kernel spectra even when the jobs share them
+static std::atomic<int> g_tune_lf_runs{0};  // WP_TUNE_LF_RUNS: 0 = up to LF_MAX_SEG runs of frames, n = at most n
+static std::atomic<int> g_tune_lf_ab{0};  // WP_TUNE_LF_SPECTRA: 1 = plain kernel spectra even when the jobs share them
 static LfGeom choose_lf(int64_t L, int64_t M, int nch)
 {
     LfGeom best;
-    if (g_tune_form == 1) return best;
+    const int tune_form = g_tune_form;
+    if (tune_form == 1) return best;
     const int64_t out_len = L + M;
     double best_cost = 0.95 * 40.0 * (double)out_len;  // measured: at 0.92 of the partitioned form's bytes the long-frame form took 0.81 of its time
-    if (g_tune_form == 2) best_cost = 1e300;
+    if (tune_form == 2) best_cost = 1e300;
     const int64_t mpad = ((M - 1 + 63) / 64) * 64;
     const int Rs[3] = {256, 128, 64};
     int64_t N2[3], hop[3];
@@ -342,7 +345,8 @@ static LfGeom choose_lf(int64_t L, int64_t M, int nch)
         okR[i] = mpad <= N2[i] / 2;
         hop[i] = N2[i] - mpad;
     }
-    const int max_runs = g_tune_lf_runs > 0 && g_tune_lf_runs < LF_MAX_SEG ? g_tune_lf_runs : LF_MAX_SEG;
+    const int tune_runs = g_tune_lf_runs;
+    const int max_runs = tune_runs > 0 && tune_runs < LF_MAX_SEG ? tune_runs : LF_MAX_SEG;
     auto consider = [&](const int64_t n[3]) {
         int64_t covered = 0, samples = 0;
         int runs = 0;
@@ -496,8 +500,8 @@ struct wp_reverb {
 };
 
 // process-wide overrides set through wp_tune (0 = the library's own choice)
-static int g_tune_B = 0, g_tune_PG = 0, g_tune_mac = 0;
-static long g_tune_pool_mb = 2048;
+static std::atomic<int> g_tune_B{0}, g_tune_PG{0}, g_tune_mac{0};
+static std::atomic<long> g_tune_pool_mb{2048};
 
 extern "C" int wp_tune(int what, int64_t value)
 {
@@ -545,7 +549,7 @@ extern "C" int wp_tune(int what, int64_t value)
 
 static int choose_B(int64_t L, int64_t M)
 {
-    if (g_tune_B) return g_tune_B;
+    if (const int b = g_tune_B) return b;
     if (L + M <= 8192) return 1024;
     // one MAC pass covers 24 partitions: IRs longer than 24*4096 samples use the larger partition
     return (M > 24 * 4096) ? 8192 : 4096;
@@ -553,7 +557,7 @@ static int choose_B(int64_t L, int64_t M)
 
 static int choose_PG(int P)
 {
-    if (g_tune_PG) return g_tune_PG;
+    if (const int pg = g_tune_PG) return pg;
     if (P <= 4) return 4;
     if (P <= 8) return 8;
     if (P <= 12) return 12;
@@ -1688,7 +1692,7 @@ static size_t g_pool_bytes = 0;
 static size_t pool_limit()
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    return (size_t)g_tune_pool_mb << 20;
+    return (size_t)g_tune_pool_mb.load() << 20;
 }
 
 extern "C" wp_buf *wp_buf_create(int nch, int64_t frames)

@@ -10,6 +10,8 @@
 // contraction, so no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "wp_fft.h"
 #include "wp_internal.h"
 #include "wp_kernel_common.h"
@@ -532,8 +534,8 @@ static hipError_t set_lds_attr(const void *fn)
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds_bytes<B>());
 }
 
-static bool g_fwd_pair = true;  // forward transform: two segments per workgroup (false: one)
-void set_fwd_pair(bool on) { g_fwd_pair = on; }
+static std::atomic<bool> g_fwd_pair{true};  // forward transform: two segments per workgroup (false: one)
+void set_fwd_pair(bool on) { g_fwd_pair.store(on, std::memory_order_relaxed); }
 
 template <int B>
 static hipError_t launch_fwd_t(bool irmode, const float *in, int64_t in_stride, int64_t in_len, c32 *Z, int T,
@@ -548,7 +550,7 @@ static hipError_t launch_fwd_t(bool irmode, const float *in, int64_t in_stride, 
     const dim3 grid(nblocks, njobs), block(B / FftPlan<B>::PT);
     if (irmode)
         hipLaunchKernelGGL((k_fft_fwd<B, true>), grid, block, (fft_lds_bytes<B, false>()), s, in, in_stride, in_len, Z, T, tables);
-    else if (g_fwd_pair && nblocks > 1 && (int64_t)nblocks * njobs >= 4096)  // (a launch that does not fill the chip is over sooner with a workgroup per segment; same bits)
+    else if (g_fwd_pair.load(std::memory_order_relaxed) && nblocks > 1 && (int64_t)nblocks * njobs >= 4096)  // (a launch that does not fill the chip is over sooner with a workgroup per segment; same bits)
         hipLaunchKernelGGL((k_fft_fwd_pair<B>), dim3((nblocks + 1) / 2, njobs), block, (fft_lds_bytes<B, false>()), s, in,
                            in_stride, in_len, Z, T, nblocks, tables);
     else

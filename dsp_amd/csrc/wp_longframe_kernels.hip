@@ -28,6 +28,8 @@
 // All three are HBM-bound streaming kernels; nothing here is a dense contraction (no MFMA).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "wp_fft.h"
 #include "wp_internal.h"
 #include "wp_kernel_common.h"
@@ -531,8 +533,9 @@ __global__ __launch_bounds__(COLS *R / 16) void k_lf_inv(const c32 *__restrict__
 
 // ---------------------------------------------------------------------------
 // launchers
-static int g_mid_jobs = 8;  // batches of at least 16 jobs: the row pass that walks 8 jobs per workgroup (0: one job)
-void set_mid_jobs(int jobs) { g_mid_jobs = jobs; }
+// (wp_tune may change it while other threads launch: a relaxed atomic, read once per launch)
+static std::atomic<int> g_mid_jobs{8};  // batches of at least 16 jobs: the row pass that walks 8 jobs per workgroup (0: one job)
+void set_mid_jobs(int jobs) { g_mid_jobs.store(jobs, std::memory_order_relaxed); }
 template <class K>
 static hipError_t lf_lds(K kernel, size_t bytes)
 {
@@ -568,7 +571,7 @@ hipError_t launch_lf_mid(bool hprep, bool ab, int R, c32 *A, c32 *Hs, const int3
                          int frames_run, int njobs, const c32 *tab, const c32 *tab_row, hipStream_t s)
 {
     if (frames_run <= 0) return hipSuccess;
-    if (!hprep && njobs >= 16 && g_mid_jobs) {
+    if (!hprep && njobs >= 16 && g_mid_jobs.load(std::memory_order_relaxed)) {
         constexpr int JB = 8;
         const size_t ldsj = sizeof(c32) * (2 * lds_points32<LF_C>() + tw_table_points<LF_C>());
         const dim3 grid((njobs + JB - 1) / JB, R / 2, frames_run);
