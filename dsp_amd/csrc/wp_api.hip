@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -275,27 +276,27 @@ static int get_tables(int dev, int B, const c32 **out)
 // the wp_tune knobs are atomics: wp_tune on one thread may run beside plan creation on another
 static std::atomic<int> g_tune_form{0};  // WP_TUNE_CONV_FORM
 
-// per-(device, R) tables of the long-frame convolution (layout: wp_internal.h)
-static std::map<std::pair<int, int>, c32 *> g_lf_tables;
+// per-(device, R, C) tables of the long-frame convolution (layout: wp_internal.h)
+static std::map<std::tuple<int, int, int>, c32 *> g_lf_tables;
 
-static int get_lf_tables(int dev, int R, const c32 **out)
+static int get_lf_tables(int dev, int R, int C, const c32 **out)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    auto key = std::make_pair(dev, R);
+    auto key = std::make_tuple(dev, R, C);
     auto it = g_lf_tables.find(key);
     if (it == g_lf_tables.end()) {
         std::vector<c32> h(LF_TABLE_POINTS, c32{0.f, 0.f});
         const double pi = 3.14159265358979323846;
-        const double Nc = (double)R * LF_C;
+        const double Nc = (double)R * C;
         auto e = [](double turns) { return c32{(float)cos(2 * 3.14159265358979323846 * turns), (float)-sin(2 * 3.14159265358979323846 * turns)}; };
         (void)pi;
         for (int a = 0; a < 256; a++) h[LF_T256 + a] = e(a / 256.0);
         for (int r = 0; r < R; r++) h[LF_ROW + r] = e(r / (2.0 * R));
-        for (int c = 0; c < LF_C; c++) h[LF_COL + c] = e(c / (2.0 * Nc));
+        for (int c = 0; c < C; c++) h[LF_COL + c] = e(c / (2.0 * Nc));
         for (int b = 0; b < 512; b++) h[LF_FLO + b] = e(b / Nc);
-        for (int a = 0; a < (int)(Nc / 512) && a < 1024; a++) h[LF_FHI + a] = e(a * 512.0 / Nc);
+        for (int a = 0; a < (int)(Nc / 512) && a < 2048; a++) h[LF_FHI + a] = e(a * 512.0 / Nc);
         for (int k = 0; k < R; k++) h[LF_WA + k] = e((k + 0.5) / (2.0 * Nc));
-        for (int k = 0; k < LF_C; k++) h[LF_WB + k] = e(k / (2.0 * LF_C));
+        for (int k = 0; k < C; k++) h[LF_WB + k] = e(k / (2.0 * C));
         c32 *d = nullptr;
         HIPCHK(hipMalloc((void **)&d, sizeof(c32) * LF_TABLE_POINTS));
         HIPCHK(hipMemcpy(d, h.data(), sizeof(c32) * LF_TABLE_POINTS, hipMemcpyHostToDevice));
@@ -306,19 +307,19 @@ static int get_lf_tables(int dev, int R, const c32 **out)
 }
 
 // Long-frame form (wp_longframe_kernels.hip) for results much longer than the impulse response:
-// frames of N2 = 2*R*LF_C samples advancing by hop = N2 - mpad.  A result is covered by up to
-// LF_MAX_SEG runs of equal frames, largest first (e.g. three frames of 2^20 samples and one of
-// 2^18 for a 60 s track with a 2 s impulse response: 3.41 M frame samples where seven frames of
-// 2^19 take 3.67 M).  Picks the cover that moves the fewest bytes (20 per frame sample + 4 per
-// output sample, + 8 per frame point when every job has a kernel spectrum of its own; every
-// further run of frames must pay for its three extra launches with 3 % of the bytes) and returns
-// none unless that is below the partitioned form's 40 bytes per output sample.
+// frames of N2 = 2*R*C samples (2^17 ... 2^21) advancing by hop = N2 - mpad.  A result is covered by up to
+// LF_MAX_SEG runs of equal frames, largest first (e.g. one frame each of 2^21, 2^20 and 2^17 samples for a
+// 60 s track with a 2 s impulse response: 3.28 M frame samples where seven frames of 2^19 take 3.67 M).
+// Picks the cover that moves the fewest bytes (20 per frame sample + 4 per output sample, + 8 per frame
+// point when every job has a kernel spectrum of its own; every further run of frames must pay for its
+// three extra launches with 3 % of the bytes) and returns none unless that is below the partitioned
+// form's 40 bytes per output sample.
 struct LfSeg {
-    int R = 0;
+    int R = 0, C = 0;  // a frame is R rows of C complex points
     int nframes = 0;
     int64_t hop = 0;
     int64_t base = 0;  // first output sample of the run
-    int64_t pts = 0;   // complex points of the run per job: nframes * R * LF_C
+    int64_t pts = 0;   // complex points of the run per job: nframes * R * C
 };
 struct LfGeom {
     int nseg = 0;  // 0: partitioned form
@@ -327,7 +328,10 @@ struct LfGeom {
     int64_t pts = 0;  // complex points per job over all runs
 };
 static std::atomic<int> g_tune_lf_runs{0};  // WP_TUNE_LF_RUNS: 0 = up to LF_MAX_SEG runs of frames, n = at most n
-static std::atomic<int> g_tune_lf_ab{0};  // WP_TUNE_LF_SPECTRA: 1 = plain kernel spectra even when the jobs share them
+static std::atomic<int> g_tune_lf_ab{0};    // WP_TUNE_LF_SPECTRA: 1 = plain kernel spectra even when the jobs share them
+static std::atomic<int> g_tune_lf_max{0};   // WP_TUNE_LF_MAX_FRAME: 0 = every frame size, n = frames of at most 2^n samples
+static std::atomic<int> g_tune_lf_min{0};   // WP_TUNE_LF_MIN_FRAME: 0 = every frame size, n = frames of at least 2^n samples
+static std::atomic<int> g_tune_lf_cost{0};  // WP_TUNE_LF_COST: 1 = covers priced by their bytes alone
 static LfGeom choose_lf(int64_t L, int64_t M, int nch)
 {
     LfGeom best;
@@ -337,80 +341,91 @@ static LfGeom choose_lf(int64_t L, int64_t M, int nch)
     double best_cost = 0.95 * 40.0 * (double)out_len;  // measured: at 0.92 of the partitioned form's bytes the long-frame form took 0.81 of its time
     if (tune_form == 2) best_cost = 1e300;
     const int64_t mpad = ((M - 1 + 63) / 64) * 64;
-    const int Rs[3] = {256, 128, 64};
-    int64_t N2[3], hop[3];
-    bool okR[3];
-    for (int i = 0; i < 3; i++) {
-        N2[i] = 2 * (int64_t)Rs[i] * LF_C;
-        okR[i] = mpad <= N2[i] / 2;
+    constexpr int NS = 5;
+    const int Rs[NS] = {256, 256, 128, 64, 32}, Cs[NS] = {LF_C_BIG, LF_C, LF_C, LF_C, LF_C};
+    int64_t N2[NS], hop[NS];
+    bool ok[NS];
+    const int max_log2 = g_tune_lf_max, min_log2 = g_tune_lf_min;
+    for (int i = 0; i < NS; i++) {
+        N2[i] = 2 * (int64_t)Rs[i] * Cs[i];
         hop[i] = N2[i] - mpad;
+        ok[i] = hop[i] * 4 >= N2[i];  // a frame advances by at least a quarter of its length
+        if (max_log2 > 0 && N2[i] > ((int64_t)1 << max_log2)) ok[i] = false;
+        if (min_log2 > 0 && N2[i] < ((int64_t)1 << min_log2)) ok[i] = false;
     }
     const int tune_runs = g_tune_lf_runs;
     const int max_runs = tune_runs > 0 && tune_runs < LF_MAX_SEG ? tune_runs : LF_MAX_SEG;
-    auto consider = [&](const int64_t n[3]) {
-        int64_t covered = 0, samples = 0;
+    int64_t n[NS] = {0, 0, 0, 0, 0};
+    auto consider = [&]() {
+        int64_t samples = 0;
         int runs = 0;
-        for (int i = 0; i < 3; i++) {
-            if (n[i] < 0 || n[i] > 65535 || (n[i] > 0 && !okR[i])) return;
-            covered += n[i] * hop[i];
+        for (int i = 0; i < NS; i++) {
             samples += n[i] * N2[i];
             runs += n[i] > 0;
         }
-        if (covered < out_len || runs == 0 || runs > max_runs) return;
         double cost = (double)samples * 20.0 + 4.0 * (double)out_len;
         if (nch > 4) cost += (double)(samples / 2) * 8.0;
+        // measured: with kernel spectra shared by the jobs the row pass over rows of LF_C_BIG points (512-thread
+        // workgroups, two per CU) takes 1.22 of the time per point that rows of LF_C points take; with a spectrum
+        // per job to stream as well it keeps up
+        else if (g_tune_lf_cost != 1) cost += 0.22 * 8.0 * (double)(n[0] * N2[0]);
         cost *= 1.0 + 0.03 * (runs - 1);
         if (cost >= best_cost) return;
         best_cost = cost;
         best = LfGeom();
         best.mpad = mpad;
         int64_t base = 0;
-        for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < NS; i++) {
             if (!n[i]) continue;
             LfSeg &g = best.seg[best.nseg++];
             g.R = Rs[i];
+            g.C = Cs[i];
             g.nframes = (int)n[i];
             g.hop = hop[i];
             g.base = base;
-            g.pts = n[i] * (int64_t)Rs[i] * LF_C;
+            g.pts = n[i] * (int64_t)Rs[i] * Cs[i];
             base += n[i] * hop[i];
             best.pts += g.pts;
         }
     };
     auto ceil_div = [](int64_t a, int64_t b) { return a <= 0 ? (int64_t)0 : (a + b - 1) / b; };
-    // n0 frames of the largest size, the rest of the result by at most 8 + 8 smaller frames
-    for (int p = 0; p < 3; p++) {
-        if (!okR[p]) continue;
-        const int64_t hi = ceil_div(out_len, hop[p]);
-        for (int64_t np = hi; np >= 0 && np >= hi - 4; np--) {
-            int64_t n[3] = {0, 0, 0};
-            n[p] = np;
-            const int64_t rem = out_len - np * hop[p];
-            if (rem <= 0 || p == 2) {
-                consider(n);
-                continue;
-            }
-            for (int q = p + 1; q < 3; q++) {
-                if (!okR[q]) continue;
-                const int64_t hq = ceil_div(rem, hop[q]);
-                for (int64_t nq = hq; nq >= 0 && nq >= hq - 8; nq--) {
-                    if (nq > 8) break;
-                    n[q] = nq;
-                    const int64_t rem2 = rem - nq * hop[q];
-                    if (q + 1 < 3) n[q + 1] = 0;
-                    if (rem2 <= 0) {
-                        consider(n);
-                    } else if (q + 1 < 3 && okR[q + 1] && ceil_div(rem2, hop[q + 1]) <= 8) {
-                        n[q + 1] = ceil_div(rem2, hop[q + 1]);
-                        consider(n);
-                        n[q + 1] = 0;
-                    }
-                }
-                n[q] = 0;
-            }
+    // runs of frames, largest size first: the first run takes up to four frames fewer than would cover what is
+    // left, a later run at most eight frames; the last run allowed covers the rest
+    std::function<void(int, int64_t, int)> rec = [&](int from, int64_t rem, int runs_left) {
+        if (rem <= 0) {
+            consider();
+            return;
         }
-    }
+        if (runs_left == 0) return;
+        const bool first = runs_left == max_runs;
+        const int64_t most = first ? 65535 : 8, span = first ? 4 : 8;
+        for (int i = from; i < NS; i++) {
+            if (!ok[i]) continue;
+            const int64_t hi = ceil_div(rem, hop[i]);
+            int64_t lo = runs_left == 1 ? hi : hi - span;
+            if (lo < 1) lo = 1;
+            for (int64_t k = hi < most ? hi : most; k >= lo; k--) {
+                n[i] = k;
+                rec(i + 1, rem - k * hop[i], runs_left - 1);
+            }
+            n[i] = 0;
+        }
+    };
+    rec(0, out_len, max_runs);
     return best;
+}
+
+extern "C" int wp_lf_cover(int64_t L, int64_t M, int nch, int64_t *runs)
+{
+    if (L < 0 || M < 1 || nch < 1 || !runs) return fail(WP_ERR_INVALID, "wp_lf_cover: bad argument");
+    const LfGeom g = choose_lf(L, M, nch);
+    for (int i = 0; i < g.nseg; i++) {
+        runs[4 * i] = 2 * (int64_t)g.seg[i].R * g.seg[i].C;
+        runs[4 * i + 1] = g.seg[i].nframes;
+        runs[4 * i + 2] = g.seg[i].hop;
+        runs[4 * i + 3] = g.seg[i].base;
+    }
+    return g.nseg;
 }
 
 // ---------------------------------------------------------------------------
@@ -446,7 +461,7 @@ struct wp_ir {
     LfGeom lf;             // long-frame geometry for results of L+M samples (lf.nseg == 0: not used)
     c32 *lf_Hs[LF_MAX_SEG];       // per run of frames: [nch][R][LF_C] real spectra of the zero-padded kernels, scaled; owned by this handle
     const c32 *lf_tab[LF_MAX_SEG];  // long-frame tables of each run's R
-    const c32 *lf_tab_row; // tables of the 2048-point row transforms
+    const c32 *lf_tab_row[LF_MAX_SEG];  // tables of each run's C-point row transforms
     bool lf_ab;            // lf_Hs holds (alpha, beta) coefficient pairs per bin (few kernels, shared by the jobs) instead of spectra
     int64_t bytes;
     wp_conv *single;   // lazily built 1-job plan for wp_convolve / wp_convolve_dev
@@ -468,7 +483,7 @@ struct wp_conv {
     int32_t *job_irch;  // device table of each job's IR channel; nullptr for one-job plans, whose
     int irch_all;       // channel travels as a launch argument (it changes from call to call)
     c32 *Z, *W;
-    bool lf;            // long-frame form: A holds, run of frames after run, [njobs][nframes][R][LF_C] instead of Z and W
+    bool lf;            // long-frame form: A holds, run of frames after run, [njobs][nframes][R][C] instead of Z and W
     c32 *A;
     hipStream_t side;   // plans with more than one run of frames: the shorter runs' inverse passes go here,
     hipEvent_t fork, join;  // beside the first run's on the caller's stream
@@ -535,6 +550,18 @@ extern "C" int wp_tune(int what, int64_t value)
         if (value < 0 || value > LF_MAX_SEG) break;
         g_tune_lf_runs = (int)value;
         return WP_OK;
+    case WP_TUNE_LF_MAX_FRAME:
+        if (value != 0 && (value < 17 || value > 21)) break;
+        g_tune_lf_max = (int)value;
+        return WP_OK;
+    case WP_TUNE_LF_MIN_FRAME:
+        if (value != 0 && (value < 17 || value > 21)) break;
+        g_tune_lf_min = (int)value;
+        return WP_OK;
+    case WP_TUNE_LF_COST:
+        if (value < 0 || value > 1) break;
+        g_tune_lf_cost = (int)value;
+        return WP_OK;
     case WP_TUNE_FWD_FORM:
         if (value < 0 || value > 2) break;
         set_fwd_pair(value != 1);
@@ -596,8 +623,8 @@ static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, 
     for (int i = 0; i < LF_MAX_SEG; i++) {
         ir->lf_Hs[i] = nullptr;
         ir->lf_tab[i] = nullptr;
+        ir->lf_tab_row[i] = nullptr;
     }
-    ir->lf_tab_row = nullptr;
     ir->lf_ab = nch <= 4 && g_tune_lf_ab != 1;
     auto free_lf = [&]() {
         for (auto &h : ir->lf_Hs) {
@@ -623,18 +650,18 @@ static wp_ir *ir_create_common(const float *ir_dev, int nch, int64_t ch_stride, 
     for (int i = 0; i < ir->lf.nseg; i++) {
         // kernel spectra of the long-frame form: the kernels as one "frame" each, through the same
         // column and row passes the signal takes, once per frame size
-        const int R = ir->lf.seg[i].R;
-        const size_t lbytes = sizeof(c32) * (size_t)nch * R * LF_C;  // of the transform; the coefficient form stores twice that
+        const int R = ir->lf.seg[i].R, C = ir->lf.seg[i].C;
+        const size_t lbytes = sizeof(c32) * (size_t)nch * R * C;  // of the transform; the coefficient form stores twice that
         c32 *tmpA = nullptr;
         hipError_t e = hipSuccess;
-        if (get_lf_tables(dev, R, &ir->lf_tab[i]) != WP_OK || get_tables(dev, LF_C, &ir->lf_tab_row) != WP_OK) {
+        if (get_lf_tables(dev, R, C, &ir->lf_tab[i]) != WP_OK || get_tables(dev, C, &ir->lf_tab_row[i]) != WP_OK) {
             free_lf();
             delete ir;
             return nullptr;
         }
         if ((e = hipMalloc((void **)&ir->lf_Hs[i], lbytes * (ir->lf_ab ? 2 : 1))) == hipSuccess) e = hipMalloc((void **)&tmpA, lbytes);
-        if (e == hipSuccess) e = launch_lf_fwd(R, ir_dev, ch_stride, M, tmpA, 1, 1, nch, 0, 0, 0, ir->lf_tab[i], s);
-        if (e == hipSuccess) e = launch_lf_mid(true, ir->lf_ab, R, tmpA, ir->lf_Hs[i], nullptr, 0, 1, 1, nch, ir->lf_tab[i], ir->lf_tab_row, s);
+        if (e == hipSuccess) e = launch_lf_fwd(R, C, ir_dev, ch_stride, M, tmpA, 1, 1, nch, 0, 0, 0, ir->lf_tab[i], s);
+        if (e == hipSuccess) e = launch_lf_mid(true, ir->lf_ab, R, C, tmpA, ir->lf_Hs[i], nullptr, 0, 1, 1, nch, ir->lf_tab[i], ir->lf_tab_row[i], s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (tmpA) (void)hipFree(tmpA);
         if (e != hipSuccess) {
@@ -780,7 +807,7 @@ extern "C" int64_t wp_ir_info(const wp_ir *ir, int which)
     case 5: return ir->L + ir->M;
     case 6: return wp_next_pot((int32_t)(ir->L + ir->M));
     case 7: return ir->bytes;
-    case 9: return ir->lf.nseg ? 2 * (int64_t)ir->lf.seg[0].R * LF_C : 0;
+    case 9: return ir->lf.nseg ? 2 * (int64_t)ir->lf.seg[0].R * ir->lf.seg[0].C : 0;
     case 10: return ir->lf.nseg;
     case 11: return 2 * ir->lf.pts;
     case 8: {
@@ -939,7 +966,7 @@ extern "C" int64_t wp_conv_info(const wp_conv *c, int which)
     case 4: return c->tchunk;
     case 5: return c->gather ? 1 : 0;
     case 6: return c->lf ? 1 : 0;
-    case 7: return c->lf ? 2 * (int64_t)c->ir->lf.seg[0].R * LF_C : 0;
+    case 7: return c->lf ? 2 * (int64_t)c->ir->lf.seg[0].R * c->ir->lf.seg[0].C : 0;
     case 8: return c->lf ? c->ir->lf.seg[0].nframes : 0;
     case 9: return c->lf ? c->ir->lf.seg[0].hop : 0;
     case 10: return c->lf ? c->ir->lf.nseg : 0;
@@ -950,7 +977,7 @@ extern "C" int64_t wp_conv_info(const wp_conv *c, int which)
         if (!c->lf || i >= c->ir->lf.nseg) return 0;
         const LfSeg &g = c->ir->lf.seg[i];
         switch ((which - 16) % 4) {
-        case 0: return 2 * (int64_t)g.R * LF_C;
+        case 0: return 2 * (int64_t)g.R * g.C;
         case 1: return g.nframes;
         case 2: return g.hop;
         case 3: return g.base;
@@ -1018,14 +1045,14 @@ static int conv_front_lf(wp_conv *c, const float *in_dev, int64_t in_stride, int
     if (c->prof) HIPCHK(hipEventRecord(c->ev[0], s));
     for (int i = 0; i < ir->lf.nseg; i++) {
         const LfSeg &g = ir->lf.seg[i];
-        HIPCHK(launch_lf_fwd(g.R, in_dev, in_stride, in_len, lf_seg_A(c, i), g.nframes, lf_frames_run(g, limit), c->njobs, g.base,
+        HIPCHK(launch_lf_fwd(g.R, g.C, in_dev, in_stride, in_len, lf_seg_A(c, i), g.nframes, lf_frames_run(g, limit), c->njobs, g.base,
                              g.hop, ir->lf.mpad, ir->lf_tab[i], s));
     }
     if (c->prof) HIPCHK(hipEventRecord(c->ev[1], s));
     for (int i = 0; i < ir->lf.nseg; i++) {
         const LfSeg &g = ir->lf.seg[i];
-        HIPCHK(launch_lf_mid(false, ir->lf_ab, g.R, lf_seg_A(c, i), ir->lf_Hs[i], c->job_irch, c->irch_all, g.nframes, lf_frames_run(g, limit),
-                             c->njobs, ir->lf_tab[i], ir->lf_tab_row, s));
+        HIPCHK(launch_lf_mid(false, ir->lf_ab, g.R, g.C, lf_seg_A(c, i), ir->lf_Hs[i], c->job_irch, c->irch_all, g.nframes, lf_frames_run(g, limit),
+                             c->njobs, ir->lf_tab[i], ir->lf_tab_row[i], s));
     }
     if (c->prof) HIPCHK(hipEventRecord(c->ev[2], s));
     return WP_OK;
@@ -1051,8 +1078,12 @@ static int conv_back_lf(wp_conv *c, int64_t limit, int nsrc, float *bus0, float 
             }
             q = c->side;
         }
-        HIPCHK(launch_lf_inv(g.R, lf_seg_A(c, i), g.nframes, fr, c->njobs, g.base, g.hop, ir->lf.mpad, nsrc, bus0, bus1, tl, vol,
-                             out_dev, out_stride, out_len, ir->lf_tab[i], q));
+        // a run that starts behind the end of the bus folds nothing: its results (if wanted) take the plain pass, one
+        // workgroup per job and tile, instead of a serial walk over the sources
+        const bool fold = bus0 && g.base < tl;
+        if (!fold && !out_dev) continue;
+        HIPCHK(launch_lf_inv(g.R, g.C, lf_seg_A(c, i), g.nframes, fr, c->njobs, g.base, g.hop, ir->lf.mpad, nsrc, fold ? bus0 : nullptr,
+                             fold ? bus1 : nullptr, tl, vol, out_dev, out_stride, out_len, ir->lf_tab[i], q));
     }
     if (forked) {
         HIPCHK(hipEventRecord(c->join, c->side));

@@ -137,8 +137,13 @@ struct Dft<4, INV> {
 // runs PT/R butterflies per thread.
 template <int B>
 struct FftPlan;
-// 64, 128 and 256 points: the strided (column) transforms of the long-frame convolution; 4, 8 or
+// 32, 64, 128 and 256 points: the strided (column) transforms of the long-frame convolution; 2, 4, 8 or
 // 16 threads of 16 points per transform, one exchange
+template <>
+struct FftPlan<32> {
+    static constexpr int PT = 16, NSTAGE = 2;
+    static constexpr int radix(int s) { return s == 0 ? 16 : 2; }
+};
 template <>
 struct FftPlan<64> {
     static constexpr int PT = 16, NSTAGE = 2;

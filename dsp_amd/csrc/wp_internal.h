@@ -5,7 +5,7 @@
 #include <stdint.h>
 
 #include "wp_fft.h"
-#include "wp_lf_layout.h"  // LF_C and the layout of a frame in the long-frame workspace
+#include "wp_lf_layout.h"  // LF_C, LF_C_BIG and the layout of a frame in the long-frame workspace
 #include "../../include/wpdsp.h"
 
 namespace wp {
@@ -49,27 +49,29 @@ hipError_t launch_big_fft(const float *src, int64_t n_real, int64_t N, int inver
                           int64_t n_out, hipStream_t s);
 
 // ---- long-frame convolution (wp_longframe_kernels.hip) ----
-// A frame of 2*Nc real samples = Nc = R*LF_C complex points; R = 64, 128 or 256.  A job's result is covered by
-// up to LF_MAX_SEG runs of equal frames (largest first); `base` is the first output sample of a run.
+// A frame of 2*Nc real samples = Nc = R*C complex points: R = 32, 64, 128 or 256 rows of C = LF_C points, or 256 rows of
+// LF_C_BIG points (2^17 ... 2^21 samples).  A job's result is covered by up to LF_MAX_SEG runs of equal frames (largest
+// first); `base` is the first output sample of a run.
 constexpr int LF_MAX_SEG = 3;
-// device table block of one R (c32 entries):
+// device table block of one (R, C) (c32 entries):
 //   [LF_T256, +256)  exp(-2*pi*i*a/256)            [LF_ROW, +256)   exp(-i*pi*r/R), r < R
-//   [LF_COL, +2048)  exp(-i*pi*c/Nc), c < LF_C     [LF_FLO, +512)   exp(-2*pi*i*b/Nc), b < 512
-//   [LF_FHI, +1024)  exp(-2*pi*i*a*512/Nc)         [LF_WA, +256)    exp(-i*pi*(k1+1/2)/Nc), k1 < R
-//   [LF_WB, +2048)   exp(-i*pi*k2/LF_C), k2 < LF_C
-constexpr int LF_T256 = 0, LF_ROW = 256, LF_COL = 512, LF_FLO = 2560, LF_FHI = 3072, LF_WA = 4096, LF_WB = 4352,
-              LF_TABLE_POINTS = 6400;
+//   [LF_COL, +4096)  exp(-i*pi*c/Nc), c < C        [LF_FLO, +512)   exp(-2*pi*i*b/Nc), b < 512
+//   [LF_FHI, +2048)  exp(-2*pi*i*a*512/Nc)         [LF_WA, +256)    exp(-i*pi*(k1+1/2)/Nc), k1 < R
+//   [LF_WB, +4096)   exp(-i*pi*k2/C), k2 < C
+constexpr int LF_T256 = 0, LF_ROW = 256, LF_COL = 512, LF_FLO = 4608, LF_FHI = 5120, LF_WA = 7168, LF_WB = 7424,
+              LF_TABLE_POINTS = 11520;
+bool lf_shape_ok(int R, int C);  // a frame shape the kernels are built for
 // nframes: frames per job in A (the stride); frames_run <= nframes: how many of them this launch handles
-hipError_t launch_lf_fwd(int R, const float *in, int64_t in_stride, int64_t in_len, c32 *A, int nframes, int frames_run,
+hipError_t launch_lf_fwd(int R, int C, const float *in, int64_t in_stride, int64_t in_len, c32 *A, int nframes, int frames_run,
                          int njobs, int64_t base, int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s);
 void set_mid_jobs(int jobs);  // WP_TUNE_MID_FORM
-// tab_row: the table block of the 2048-point plan (row transforms)
+// tab_row: the table block of the C-point plan (row transforms)
 // ab: Hs holds (alpha, beta) coefficient pairs, 16 bytes per bin (kernel spectra shared by the jobs), instead of spectra
-hipError_t launch_lf_mid(bool hprep, bool ab, int R, c32 *A, c32 *Hs, const int32_t *job_irch, int irch_all, int nframes,
+hipError_t launch_lf_mid(bool hprep, bool ab, int R, int C, c32 *A, c32 *Hs, const int32_t *job_irch, int irch_all, int nframes,
                          int frames_run, int njobs, const c32 *tab, const c32 *tab_row, hipStream_t s);
 // bus0 == nullptr: plain results for every job; otherwise the bus fold over nsrc stereo sources (jobs 2s, 2s+1),
 // with the per-job results too when out != nullptr
-hipError_t launch_lf_inv(int R, const c32 *A, int nframes, int frames_run, int njobs, int64_t base, int64_t hop, int64_t mpad, int nsrc,
+hipError_t launch_lf_inv(int R, int C, const c32 *A, int nframes, int frames_run, int njobs, int64_t base, int64_t hop, int64_t mpad, int nsrc,
                          float *bus0, float *bus1, int64_t tl, const double *vol, float *out, int64_t out_stride,
                          int64_t out_len, const c32 *tab, hipStream_t s);
 // out[job][i] += prev[job][i], i < prev_len (the carried reverb tail, lib/impulse-reverb.js:14-16)

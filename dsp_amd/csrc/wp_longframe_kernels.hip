@@ -67,12 +67,12 @@ __device__ __forceinline__ TwTables<R> lf_col_tables(const c32 *__restrict__ tab
 // Forward column pass.  Workgroup = tile of 32 columns of one frame of one job; thread = (column,
 // j) with R/16 threads per column transform.  IRMODE: the "frame" is the impulse response itself,
 // starting at sample 0.
-template <int R>
+template <int R, int C>
 __global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_fwd(const float *__restrict__ in, int64_t in_stride, int64_t in_len,
                                                             c32 *__restrict__ A, int nframes, int64_t base, int64_t hop,
                                                             int64_t mpad, const c32 *__restrict__ tab)
 {
-    constexpr int C = LF_C, NTF = R / 16, PT = 16;
+    constexpr int NTF = R / 16, PT = 16;
     constexpr int64_t Nc = (int64_t)R * C;
     extern __shared__ __align__(16) unsigned char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
@@ -82,12 +82,23 @@ __global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_fwd(const float *__restr
     const TwTables<R> tw = lf_col_tables<R>(tab);
     const float *x = in + (int64_t)job * in_stride;
     const int64_t start = base + (int64_t)frame * hop - mpad;  // sample at frame position 0 (base: first output sample of this run of frames)
-    const bool fast = start >= 0 && start + 2 * Nc <= in_len && ((reinterpret_cast<uintptr_t>(x + start) & 7) == 0);
-
+    // When the frame starts on an 8-byte boundary (the same for every pair of it), a sample pair is one 8-byte load
+    // through a buffer descriptor over the job's input: the hardware returns zeros for pairs outside it (offsets of
+    // pairs ahead of the input wrap to out of range), so a frame that starts ahead of the input or ends behind it
+    // (the first and the last of a result) loads like any other.  A pair that straddles the input's end is patched.
+    const bool al = (reinterpret_cast<uintptr_t>(x + start) & 7) == 0 && in_len < ((int64_t)1 << 29);  // byte offsets of every pair, in or out of range, stay below 2^32
     c32 v[PT];
-    if (fast) {
-        const c32 *xs = reinterpret_cast<const c32 *>(x + start) + c;
-        static_for<0, PT>([&](auto t) { v[t] = xs[(int64_t)(j + int(t) * NTF) * C]; });
+    if (al) {
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (uint32_t)in_len * 4u, 0x00020000);
+        static_for<0, PT>([&](auto t) {
+            const int64_t g = start + 2 * ((int64_t)(j + int(t) * NTF) * C + c);
+            const v2f p = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)((uint32_t)g * 4u), 0, 0));
+            v[t] = c32{p.x, p.y};
+        });
+        static_for<0, PT>([&](auto t) {
+            const int64_t g = start + 2 * ((int64_t)(j + int(t) * NTF) * C + c);
+            if (g + 1 == in_len) v[t] = c32{x[g], 0.0f};
+        });
     } else {
         static_for<0, PT>([&](auto t) {
             const int64_t g = start + 2 * ((int64_t)(j + int(t) * NTF) * C + c);
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_fwd(const float *__restr
     c32 *a = A + ((int64_t)job * nframes + frame) * Nc + lf_col_off(c);
     stage_store<R, 1, false>(j, v, [&](int k1, c32 val, auto t, auto u) {
         // k1 = j' + 16*t with j' < 16: the row offset is a constant of t plus 64*j'
-        st_nt(a + (k1 - 16 * int(t)) * LF_CC + lf_row_off(16 * int(t)), cmul(val, cmul(wj[u], pw[t])));
+        st_nt(a + (k1 - 16 * int(t)) * LF_CC + lf_row_off(16 * int(t), C), cmul(val, cmul(wj[u], pw[t])));
     });
 }
 
@@ -141,20 +152,20 @@ __device__ __forceinline__ c32 lf_pair_product(c32x2 h, c32 z, c32 zp)
     return y;
 }
 
-template <bool HPREP, bool AB>
-__global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__restrict__ Hs, const int32_t *__restrict__ job_irch,
+template <bool HPREP, bool AB, int C>
+__global__ __launch_bounds__(C / 8) void k_lf_mid(c32 *__restrict__ A, c32 *__restrict__ Hs, const int32_t *__restrict__ job_irch,
                                                 int irch_all, int R, int nframes, const c32 *__restrict__ tab,
                                                 const c32 *__restrict__ tab_row)
 {
-    constexpr int C = LF_C, NT = C / 16;
+    constexpr int NT = C / 16, WGT = 2 * NT;  // threads per row transform, per workgroup
     extern __shared__ __align__(16) unsigned char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
     c32 *tws = lds + 2 * C;  // not filled: this kernel's row transforms read their tables from global memory
-    const int tid = threadIdx.x, half = tid >> 7, ft = tid & (NT - 1);
+    const int tid = threadIdx.x, half = tid / NT, ft = tid & (NT - 1);
     const int job = blockIdx.x, k1 = blockIdx.y, frame = blockIdx.z;  // jobs fastest: neighbours share the kernel spectrum rows
     const int64_t Nc = (int64_t)R * C;
     const int row = half ? R - 1 - k1 : k1;
-    c32 *rowp = A + ((int64_t)job * nframes + frame) * R * C + lf_row_off(row);  // point n of the row: rowp + lf_col_off(n)
+    c32 *rowp = A + ((int64_t)job * nframes + frame) * R * C + lf_row_off(row, C);  // point n of the row: rowp + lf_col_off(n)
     c32 *ldsrow = lds + half * C;
     const TwTables<C> tw = load_tables<C, false>(tab_row, tws, ft);
 
@@ -162,8 +173,8 @@ __global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__rest
     stage_load<C, 0>(ft, v, [&](int n) { return ld_nt(rowp + lf_col_off(n)); });
     const int irch = HPREP ? job : (job_irch ? job_irch[job] : irch_all);
     // plain spectra lie like a frame of A (a job that reads its own from HBM streams them the same way)
-    c32 *ha = AB ? Hs + ((int64_t)irch * R + k1) * C * 2 : Hs + (int64_t)irch * R * C + lf_row_off(k1);
-    c32 *hb = AB ? Hs + ((int64_t)irch * R + (R - 1 - k1)) * C * 2 : Hs + (int64_t)irch * R * C + lf_row_off(R - 1 - k1);
+    c32 *ha = AB ? Hs + ((int64_t)irch * R + k1) * C * 2 : Hs + (int64_t)irch * R * C + lf_row_off(k1, C);
+    c32 *hb = AB ? Hs + ((int64_t)irch * R + (R - 1 - k1)) * C * 2 : Hs + (int64_t)irch * R * C + lf_row_off(R - 1 - k1, C);
     middle_stages<C, false>(ft, v, ldsrow, tw);
     __syncthreads();  // every lane has taken its last-stage inputs out of LDS
     stage_store<C, FftPlan<C>::NSTAGE - 1, false>(ft, v, [&](int i, c32 val, int, int) { ldsrow[lds_pad(i)] = val; });
@@ -173,8 +184,8 @@ __global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__rest
     const c32 wa = tab[LF_WA + k1];
     const float scale = 1.0f / (8.0f * (float)Nc);
 #pragma unroll
-    for (int q = 0; q < C / 256; q++) {
-        const int k2 = tid + 256 * q, p2 = C - 1 - k2;
+    for (int q = 0; q < C / WGT; q++) {
+        const int k2 = tid + WGT * q, p2 = C - 1 - k2;
         const c32 za = lds[lds_pad(k2)], zb = lds[C + lds_pad(p2)];
         if constexpr (!HPREP && AB) {
             const c32x2 pa = reinterpret_cast<const c32x2 *>(ha)[k2], pb = reinterpret_cast<const c32x2 *>(hb)[p2];
@@ -222,18 +233,18 @@ __global__ __launch_bounds__(256) void k_lf_mid(c32 *__restrict__ A, c32 *__rest
 // else is loaded from global memory ahead of the kernel spectrum (a younger load's wait would also wait
 // for the rows in flight): the row plan's tables are copied to LDS, the split factors kept in registers.
 // Same arithmetic as k_lf_mid<false>.
-template <int JB, bool AB>
-__global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const c32 *__restrict__ Hs,
+template <int JB, bool AB, int C>
+__global__ __launch_bounds__(C / 8) void k_lf_mid_jobs(c32 *__restrict__ A, const c32 *__restrict__ Hs,
                                                      const int32_t *__restrict__ job_irch, int irch_all, int R, int nframes,
                                                      int njobs, const c32 *__restrict__ tab, const c32 *__restrict__ tab_row)
 {
-    constexpr int C = LF_C, NT = C / 16, LAST = FftPlan<C>::NSTAGE - 1, NSL = plan_ns<C>(LAST);
+    constexpr int NT = C / 16, WGT = 2 * NT, LAST = FftPlan<C>::NSTAGE - 1, NSL = plan_ns<C>(LAST);
     static_assert(FftPlan<C>::radix(0) == 16 && FftPlan<C>::PT == 16, "one stage-0 butterfly per thread");
     extern __shared__ __align__(16) unsigned char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
     constexpr int CP = lds_points32<C>();  // a row in LDS: one pad element per 32 (lds_pad32)
     c32 *tws = lds + 2 * CP;
-    const int tid = threadIdx.x, half = tid >> 7, ft = tid & (NT - 1);
+    const int tid = threadIdx.x, half = tid / NT, ft = tid & (NT - 1);
     const int k1 = blockIdx.y, frame = blockIdx.z;
     const int job0 = blockIdx.x * JB, jend = job0 + JB < njobs ? job0 + JB : njobs;
     const int64_t Nc = (int64_t)R * C;
@@ -242,17 +253,17 @@ __global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const 
     const TwTables<C> tw = load_tables<C, true>(tab_row, tws, tid);  // first used behind the first exchange's barrier
     // a row access = a base that is the same in every lane (job, frame, point group; kept in scalar registers by
     // an empty asm, or the optimiser folds it into sixteen per-lane 64-bit offsets) + one per-lane offset
-    c32 *__restrict__ Arow = A + lf_row_off(row);
+    c32 *__restrict__ Arow = A + lf_row_off(row, C);
     auto fetch = [&](int job, c32 *v) {
-        static_for<0, 16>([&](auto t) {  // point ft + 128*t: chunk (ft >> 6) + 2*t, column ft & 63 of it
+        static_for<0, 16>([&](auto t) {  // point ft + NT*t: chunk (ft >> 6) + (NT/64)*t, column ft & 63 of it
             int64_t at = ((int64_t)job * nframes + frame) * Nc + lf_col_off(int(t) * (C / 16));
             asm volatile("" : "+s"(at));
             v[t] = ld_nt(Arow + lf_col_off(ft) + at);
         });
     };
     const c32 wa = tab[LF_WA + k1];
-    c32 wk[AB ? 1 : C / 256];  // exp(-i*pi*(k+1/2)/Nc) of this thread's bins k = k1 + R*k2, k2 = tid + 256*q
-    if constexpr (!AB) static_for<0, C / 256>([&](auto q) { wk[q] = cmul(wa, tab[LF_WB + tid + 256 * int(q)]); });
+    c32 wk[AB ? 1 : C / WGT];  // exp(-i*pi*(k+1/2)/Nc) of this thread's bins k = k1 + R*k2, k2 = tid + WGT*q
+    if constexpr (!AB) static_for<0, C / WGT>([&](auto q) { wk[q] = cmul(wa, tab[LF_WB + tid + WGT * int(q)]); });
 
     c32 v[16], vn[16];
     fetch(job0, vn);
@@ -267,8 +278,8 @@ __global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const 
         for (int i = 0; i < 16; i++) v[i] = vn[i];
         if (job + 1 < jend) fetch(job + 1, vn);
         const int irch = job_irch ? job_irch[job] : irch_all;
-        const c32 *ha = AB ? Hs + ((int64_t)irch * R + k1) * C * 2 : Hs + (int64_t)irch * R * C + lf_row_off(k1);
-        const c32 *hb = AB ? Hs + ((int64_t)irch * R + (R - 1 - k1)) * C * 2 : Hs + (int64_t)irch * R * C + lf_row_off(R - 1 - k1);
+        const c32 *ha = AB ? Hs + ((int64_t)irch * R + k1) * C * 2 : Hs + (int64_t)irch * R * C + lf_row_off(k1, C);
+        const c32 *hb = AB ? Hs + ((int64_t)irch * R + (R - 1 - k1)) * C * 2 : Hs + (int64_t)irch * R * C + lf_row_off(R - 1 - k1, C);
         // the thread indices are hidden from the optimiser once per job (and once more between the two
         // transforms): every LDS address and twiddle power derived from them would otherwise be computed
         // once, ahead of the loop, and held in some 150 registers across it
@@ -294,11 +305,11 @@ __global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const 
             ldsrow[lds_pad32(i - int(t) * NSL) + pad32_store_k<NSL>(int(t))] = val;
         });
         __syncthreads();
-        // bins k2 = tl + 256*q of row k1 and their partners C-1-k2 of the other row: 264 padded positions per q
+        // bins k2 = tl + WGT*q of row k1 and their partners C-1-k2 of the other row: WGT + WGT/32 padded positions per q
         c32 *za_p = lds + lds_pad32(tl), *zb_p = lds + CP + lds_pad32(C - 1 - tl);
-        static_for<0, C / 256>([&](auto q) {
-            const int k2 = tl + 256 * int(q), p2 = C - 1 - k2;
-            c32 &za_s = za_p[264 * int(q)], &zb_s = zb_p[-264 * int(q)];
+        static_for<0, C / WGT>([&](auto q) {
+            const int k2 = tl + WGT * int(q), p2 = C - 1 - k2;
+            c32 &za_s = za_p[(WGT + WGT / 32) * int(q)], &zb_s = zb_p[-(WGT + WGT / 32) * int(q)];
             const c32 za = za_s, zb = zb_s;
             if constexpr (AB) {
                 const c32x2 pa = reinterpret_cast<const c32x2 *>(ha)[k2], pb = reinterpret_cast<const c32x2 *>(hb)[p2];
@@ -333,13 +344,13 @@ __global__ __launch_bounds__(256) void k_lf_mid_jobs(c32 *__restrict__ A, const 
 // source's tile prefetched; otherwise blockIdx.z is the job.  WRITE: store the job's samples.
 // COLS: columns per tile (32, or 16 for R = 256 so that the workgroup stays at 256 threads: with 512 the
 // bus-fold variants need more registers than two waves per SIMD leave and spill).
-template <int R, int COLS, bool MIX, bool WRITE>
+template <int R, int C, int COLS, bool MIX, bool WRITE>
 __global__ __launch_bounds__(COLS *R / 16) void k_lf_inv(const c32 *__restrict__ A, int nframes, int64_t base, int64_t hop,
                                                             int64_t mpad, int nsrc, float *__restrict__ bus0, float *__restrict__ bus1,
                                                             int64_t tl, const double *__restrict__ vol, float *__restrict__ out,
                                                             int64_t out_stride, int64_t out_len, const c32 *__restrict__ tab)
 {
-    constexpr int C = LF_C, NTF = R / 16, PT = 16;
+    constexpr int NTF = R / 16, PT = 16;
     constexpr int64_t Nc = (int64_t)R * C;
     constexpr int R1 = FftPlan<R>::radix(1), NB = PT / R1;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(COLS *R / 16) void k_lf_inv(const c32 *__restrict__
     const c32 *__restrict__ At = A + (j * LF_CC + lf_col_off(c));
     auto fetch = [&](int job, c32 *v) {
         static_for<0, PT>([&](auto t) {
-            int64_t at = ((int64_t)job * nframes + frame) * Nc + lf_row_off(int(t) * NTF);
+            int64_t at = ((int64_t)job * nframes + frame) * Nc + lf_row_off(int(t) * NTF, C);
             asm volatile("" : "+s"(at));
             v[t] = ld_nt(At + at);
         });
@@ -543,47 +554,69 @@ static hipError_t lf_lds(K kernel, size_t bytes)
     return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int R>
-static hipError_t lf_fwd_t(const float *in, int64_t in_stride, int64_t in_len, c32 *A, int nframes, int frames_run, int njobs,
-                           int64_t base, int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s)
+// frame shapes (rows x columns) the kernels are instantiated for: 2^17 ... 2^21 samples
+bool lf_shape_ok(int R, int C) { return (C == LF_C && (R == 32 || R == 64 || R == 128 || R == 256)) || (C == LF_C_BIG && R == 256); }
+// f(ic<R>, ic<C>) for the shape given at run time
+template <class F>
+static hipError_t lf_dispatch(int R, int C, F &&f)
 {
-    const size_t lds = sizeof(c32) * R * LF_COLS;
-    if (hipError_t e = lf_lds(k_lf_fwd<R>, lds)) return e;
-    hipLaunchKernelGGL((k_lf_fwd<R>), dim3(LF_C / LF_COLS, frames_run, njobs), dim3(LF_COLS * R / 16), lds, s, in, in_stride, in_len,
-                       A, nframes, base, hop, mpad, tab);
-    return hipGetLastError();
-}
-
-hipError_t launch_lf_fwd(int R, const float *in, int64_t in_stride, int64_t in_len, c32 *A, int nframes, int frames_run,
-                         int njobs, int64_t base, int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s)
-{
-    if (frames_run <= 0) return hipSuccess;
-    if (nframes > 65535 || njobs > 65535) return hipErrorInvalidValue;
+    if (C == LF_C_BIG && R == 256) return f(ic<256>{}, ic<LF_C_BIG>{});
+    if (C != LF_C) return hipErrorInvalidValue;
     switch (R) {
-    case 64: return lf_fwd_t<64>(in, in_stride, in_len, A, nframes, frames_run, njobs, base, hop, mpad, tab, s);
-    case 128: return lf_fwd_t<128>(in, in_stride, in_len, A, nframes, frames_run, njobs, base, hop, mpad, tab, s);
-    case 256: return lf_fwd_t<256>(in, in_stride, in_len, A, nframes, frames_run, njobs, base, hop, mpad, tab, s);
+    case 32: return f(ic<32>{}, ic<LF_C>{});
+    case 64: return f(ic<64>{}, ic<LF_C>{});
+    case 128: return f(ic<128>{}, ic<LF_C>{});
+    case 256: return f(ic<256>{}, ic<LF_C>{});
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_lf_mid(bool hprep, bool ab, int R, c32 *A, c32 *Hs, const int32_t *job_irch, int irch_all, int nframes,
-                         int frames_run, int njobs, const c32 *tab, const c32 *tab_row, hipStream_t s)
+template <int R, int C>
+static hipError_t lf_fwd_t(const float *in, int64_t in_stride, int64_t in_len, c32 *A, int nframes, int frames_run, int njobs,
+                           int64_t base, int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s)
+{
+    const size_t lds = sizeof(c32) * R * LF_COLS;
+    if (hipError_t e = lf_lds(k_lf_fwd<R, C>, lds)) return e;
+    hipLaunchKernelGGL((k_lf_fwd<R, C>), dim3(C / LF_COLS, frames_run, njobs), dim3(LF_COLS * R / 16), lds, s, in, in_stride, in_len,
+                       A, nframes, base, hop, mpad, tab);
+    return hipGetLastError();
+}
+
+hipError_t launch_lf_fwd(int R, int C, const float *in, int64_t in_stride, int64_t in_len, c32 *A, int nframes, int frames_run,
+                         int njobs, int64_t base, int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s)
 {
     if (frames_run <= 0) return hipSuccess;
+    if (nframes > 65535 || njobs > 65535) return hipErrorInvalidValue;
+    return lf_dispatch(R, C, [&](auto r, auto c) {
+        return lf_fwd_t<int(r), int(c)>(in, in_stride, in_len, A, nframes, frames_run, njobs, base, hop, mpad, tab, s);
+    });
+}
+
+template <int C>
+static hipError_t lf_mid_t(bool hprep, bool ab, int R, c32 *A, c32 *Hs, const int32_t *job_irch, int irch_all, int nframes,
+                           int frames_run, int njobs, const c32 *tab, const c32 *tab_row, hipStream_t s)
+{
+    const dim3 block(C / 8);
     if (!hprep && njobs >= 16 && g_mid_jobs.load(std::memory_order_relaxed)) {
         constexpr int JB = 8;
-        const size_t ldsj = sizeof(c32) * (2 * lds_points32<LF_C>() + tw_table_points<LF_C>());
+        const size_t ldsj = sizeof(c32) * (2 * lds_points32<C>() + tw_table_points<C>());
         const dim3 grid((njobs + JB - 1) / JB, R / 2, frames_run);
-        if (ab)
-            hipLaunchKernelGGL((k_lf_mid_jobs<JB, true>), grid, dim3(256), ldsj, s, A, Hs, job_irch, irch_all, R, nframes, njobs, tab, tab_row);
-        else
-            hipLaunchKernelGGL((k_lf_mid_jobs<JB, false>), grid, dim3(256), ldsj, s, A, Hs, job_irch, irch_all, R, nframes, njobs, tab, tab_row);
+        if (ab) {
+            if (hipError_t e = lf_lds(k_lf_mid_jobs<JB, true, C>, ldsj)) return e;
+            hipLaunchKernelGGL((k_lf_mid_jobs<JB, true, C>), grid, block, ldsj, s, A, Hs, job_irch, irch_all, R, nframes, njobs, tab, tab_row);
+        } else {
+            if (hipError_t e = lf_lds(k_lf_mid_jobs<JB, false, C>, ldsj)) return e;
+            hipLaunchKernelGGL((k_lf_mid_jobs<JB, false, C>), grid, block, ldsj, s, A, Hs, job_irch, irch_all, R, nframes, njobs, tab, tab_row);
+        }
         return hipGetLastError();
     }
-    const size_t lds = sizeof(c32) * 2 * LF_C;
-    const dim3 grid(njobs, R / 2, frames_run), block(256);
-#define WP_MID(H, B) hipLaunchKernelGGL((k_lf_mid<H, B>), grid, block, lds, s, A, Hs, job_irch, irch_all, R, nframes, tab, tab_row)
+    const size_t lds = sizeof(c32) * 2 * C;
+    const dim3 grid(njobs, R / 2, frames_run);
+#define WP_MID(H, B)                                                                                                              \
+    do {                                                                                                                          \
+        if (hipError_t e = lf_lds(k_lf_mid<H, B, C>, lds)) return e;                                                              \
+        hipLaunchKernelGGL((k_lf_mid<H, B, C>), grid, block, lds, s, A, Hs, job_irch, irch_all, R, nframes, tab, tab_row);        \
+    } while (0)
     if (hprep && ab)
         WP_MID(true, true);
     else if (hprep)
@@ -596,7 +629,31 @@ hipError_t launch_lf_mid(bool hprep, bool ab, int R, c32 *A, c32 *Hs, const int3
     return hipGetLastError();
 }
 
-template <int R>
+hipError_t launch_lf_mid(bool hprep, bool ab, int R, int C, c32 *A, c32 *Hs, const int32_t *job_irch, int irch_all, int nframes,
+                         int frames_run, int njobs, const c32 *tab, const c32 *tab_row, hipStream_t s)
+{
+    if (frames_run <= 0) return hipSuccess;
+    if (!lf_shape_ok(R, C)) return hipErrorInvalidValue;
+    if (C == LF_C_BIG) return lf_mid_t<LF_C_BIG>(hprep, ab, R, A, Hs, job_irch, irch_all, nframes, frames_run, njobs, tab, tab_row, s);
+    return lf_mid_t<LF_C>(hprep, ab, R, A, Hs, job_irch, irch_all, nframes, frames_run, njobs, tab, tab_row, s);
+}
+
+// compute units of a device (asked once per device)
+static int lf_cu_count()
+{
+    static std::atomic<int> ncu[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = ncu[dev].load(std::memory_order_relaxed);
+    if (!n) {
+        hipDeviceProp_t prop;
+        n = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        ncu[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+template <int R, int C>
 static hipError_t lf_inv_t(const c32 *A, int nframes, int frames_run, int njobs, int64_t base, int64_t hop, int64_t mpad, int nsrc, float *bus0, float *bus1,
                            int64_t tl, const double *vol, float *out, int64_t out_stride, int64_t out_len, const c32 *tab,
                            hipStream_t s)
@@ -610,28 +667,22 @@ static hipError_t lf_inv_t(const c32 *A, int nframes, int frames_run, int njobs,
         // speed each: the pass takes (rounds of workgroups) x (workgroups per CU).  Two per CU fit; when one per
         // CU needs fewer such units (e.g. 768 workgroups on 256 CUs: 3 against 2 x 2), ask for more LDS than
         // two workgroups can share.
-        static int ncu = 0;
-        if (!ncu) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-            if (ncu <= 0) ncu = 256;
-        }
-        const int64_t units = (int64_t)(LF_C / COLS) * frames_run * 2;
+        const int ncu = lf_cu_count();
+        const int64_t units = (int64_t)(C / COLS) * frames_run * 2;
         const int64_t one = (units + ncu - 1) / ncu, two = 2 * ((units + 2 * ncu - 1) / (2 * ncu));
         if (one < two && lds < 84 * 1024) lds = 84 * 1024;
     }
     if (!bus0) {
-        if (hipError_t e = lf_lds(k_lf_inv<R, COLS, false, true>, lds)) return e;
-        hipLaunchKernelGGL((k_lf_inv<R, COLS, false, true>), dim3(LF_C / COLS, frames_run, njobs), block, lds, s, A, nframes, base, hop, mpad,
+        if (hipError_t e = lf_lds(k_lf_inv<R, C, COLS, false, true>, lds)) return e;
+        hipLaunchKernelGGL((k_lf_inv<R, C, COLS, false, true>), dim3(C / COLS, frames_run, njobs), block, lds, s, A, nframes, base, hop, mpad,
                            nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab);
     } else if (out) {
-        if (hipError_t e = lf_lds(k_lf_inv<R, COLS, true, true>, lds)) return e;
-        hipLaunchKernelGGL((k_lf_inv<R, COLS, true, true>), dim3(LF_C / COLS, frames_run, 2), block, lds, s, A, nframes, base, hop, mpad, nsrc,
+        if (hipError_t e = lf_lds(k_lf_inv<R, C, COLS, true, true>, lds)) return e;
+        hipLaunchKernelGGL((k_lf_inv<R, C, COLS, true, true>), dim3(C / COLS, frames_run, 2), block, lds, s, A, nframes, base, hop, mpad, nsrc,
                            bus0, bus1, tl, vol, out, out_stride, out_len, tab);
     } else {
-        if (hipError_t e = lf_lds(k_lf_inv<R, COLS, true, false>, lds)) return e;
-        hipLaunchKernelGGL((k_lf_inv<R, COLS, true, false>), dim3(LF_C / COLS, frames_run, 2), block, lds, s, A, nframes, base, hop, mpad, nsrc,
+        if (hipError_t e = lf_lds(k_lf_inv<R, C, COLS, true, false>, lds)) return e;
+        hipLaunchKernelGGL((k_lf_inv<R, C, COLS, true, false>), dim3(C / COLS, frames_run, 2), block, lds, s, A, nframes, base, hop, mpad, nsrc,
                            bus0, bus1, tl, vol, out, out_stride, out_len, tab);
     }
     return hipGetLastError();
@@ -639,18 +690,15 @@ static hipError_t lf_inv_t(const c32 *A, int nframes, int frames_run, int njobs,
 
 // bus0 == nullptr: plain results for every job; otherwise the bus fold over nsrc stereo sources,
 // with the per-job results too when out != nullptr
-hipError_t launch_lf_inv(int R, const c32 *A, int nframes, int frames_run, int njobs, int64_t base, int64_t hop, int64_t mpad, int nsrc,
+hipError_t launch_lf_inv(int R, int C, const c32 *A, int nframes, int frames_run, int njobs, int64_t base, int64_t hop, int64_t mpad, int nsrc,
                          float *bus0, float *bus1, int64_t tl, const double *vol, float *out, int64_t out_stride,
                          int64_t out_len, const c32 *tab, hipStream_t s)
 {
     if (frames_run <= 0) return hipSuccess;
     if (nframes > 65535 || njobs > 65535) return hipErrorInvalidValue;
-    switch (R) {
-    case 64: return lf_inv_t<64>(A, nframes, frames_run, njobs, base, hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab, s);
-    case 128: return lf_inv_t<128>(A, nframes, frames_run, njobs, base, hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab, s);
-    case 256: return lf_inv_t<256>(A, nframes, frames_run, njobs, base, hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab, s);
-    }
-    return hipErrorInvalidValue;
+    return lf_dispatch(R, C, [&](auto r, auto c) {
+        return lf_inv_t<int(r), int(c)>(A, nframes, frames_run, njobs, base, hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab, s);
+    });
 }
 
 __global__ void k_add_prev(float *__restrict__ out, int64_t out_stride, const float *__restrict__ prev, int64_t prev_stride,

@@ -78,6 +78,12 @@ void wp_ir_destroy(wp_ir *ir);
  * 9 frame length of the long-frame form's first run of frames (0: results of L+M samples use the
  * partitioned form), 10 runs of equal frames, 11 frame samples per job over all runs. */
 int64_t wp_ir_info(const wp_ir *ir, int which);
+/* Host only (no GPU needed, like the integer helpers): the cover by runs of equal frames that an
+ * IR handle of nch channels would get for results of L+M samples (one go of lib/convolve.js:564-586
+ * with input.length = L), under the current wp_tune settings.  Returns the number of runs (0: the
+ * partitioned form) and writes, per run, frame length in samples, frames per job, samples a frame
+ * advances by, first output sample into runs[4*i .. 4*i+3] (room for 3 runs). */
+int wp_lf_cover(int64_t L, int64_t M, int nch, int64_t *runs /* 12 */);
 
 /* ---- convolution: lib/convolve.js:564-586 fftConvolution(...) -> go(input) - */
 /* One go(input): ch picks the IR channel; in_len <= reference FFT length, else
@@ -110,8 +116,11 @@ int wp_kernel_from_spectrum(const float *spectrum /* 2N */, int64_t N, int64_t M
  * serving loops, harnesses that forbid hipMalloc): the block spectra live in a
  * static device array of WP_NOALLOC_WORKSPACE_BYTES that the library's code object
  * carries (one copy per GPU, held until the process ends), and the call makes no
- * hipMalloc/hipFree or other allocating call.  Same kernels and geometry as
- * wp_convolve_dev, so the result is bit-identical to it.  Limits: the result
+ * hipMalloc/hipFree or other allocating call.  It always runs the partitioned form
+ * (same kernels and geometry as a wp_convolve_dev plan in that form, so the result is
+ * bit-identical to such a plan's); for inputs many times longer than the impulse
+ * response wp_convolve_dev itself may choose the long-frame form, whose results differ
+ * from these in the last bits (both within 1e-5 of the reference's).  Limits: the result
  * length L+M must satisfy ceil((L+M)/B)*B <= WP_NOALLOC_WORKSPACE_BYTES/16 complex
  * points (B = wp_ir_info(ir, 3); with B = 4096 that is L+M <= 524288 samples, 10.9 s
  * at 48 kHz), else WP_ERR_RANGE; inputs that wrap in the reference's FFT are
@@ -324,6 +333,9 @@ double wp_bpm_from_beat_rate(double sample_rate, int64_t beat_rate);
 #define WP_TUNE_LF_RUNS 6   /* long-frame form: at most this many runs of equal frames per result (1..3; 1 = one frame size) */
 #define WP_TUNE_MID_FORM 7  /* long-frame row pass: 1 one job per workgroup, 2 eight (the default for batches; takes effect at once) */
 #define WP_TUNE_LF_SPECTRA 8 /* long-frame kernel spectra of IR handles created afterwards: 1 plain spectra, 2 product coefficients when the jobs share few kernels (default) */
+#define WP_TUNE_LF_MAX_FRAME 9  /* long-frame form: frames of at most 2^n samples (17..21; 0 = no limit) for IR handles created afterwards */
+#define WP_TUNE_LF_MIN_FRAME 10 /* long-frame form: frames of at least 2^n samples (17..21; 0 = no limit) */
+#define WP_TUNE_LF_COST 11 /* long-frame form: 1 = choose the cover by its bytes alone (0: measured per-shape kernel rates weigh in) */
 #define WP_TUNE_FWD_FORM 4  /* forward transform: 1 one segment per workgroup, 2 two (the default; takes effect at once) */
 #define WP_TUNE_POOL_MB 3   /* cap of the wp_buf recycling pool in MiB (default 2048; 0 disables it) */
 int wp_tune(int what, int64_t value);

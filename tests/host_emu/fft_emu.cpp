@@ -165,41 +165,44 @@ static int test_pad32()
     for (int i = 0; i < B; i++) {
         if (lds_pad32(i) < 0 || lds_pad32(i) >= lds_points32<B>() || seen[lds_pad32(i)]++) bad++;
     }
-    // the row pass's bin pairs: k2 = tid + 256*q and C-1-k2, 264 padded positions per q
-    for (int tid = 0; tid < 256 && B == 2048; tid++)
-        for (int q = 0; q < B / 256; q++) {
-            if (lds_pad32(tid + 256 * q) != lds_pad32(tid) + 264 * q) bad++;
-            if (lds_pad32(B - 1 - tid - 256 * q) != lds_pad32(B - 1 - tid) - 264 * q) bad++;
+    // the row pass's bin pairs: k2 = tid + W*q and C-1-k2 with W = C/8 threads per workgroup: W + W/32 padded positions per q
+    constexpr int W = B / 8;
+    for (int tid = 0; tid < W && (B == 2048 || B == 4096); tid++)
+        for (int q = 0; q < B / W; q++) {
+            if (lds_pad32(tid + W * q) != lds_pad32(tid) + (W + W / 32) * q) bad++;
+            if (lds_pad32(B - 1 - tid - W * q) != lds_pad32(B - 1 - tid) - (W + W / 32) * q) bad++;
         }
     return bad;
 }
 
-// Layout of a long-frame frame in the workspace (wp_lf_layout.h): every point of an R x LF_C frame has a place of
+// Layout of a long-frame frame in the workspace (wp_lf_layout.h): every point of an R x C frame has a place of
 // its own inside the frame, and the offsets split the way the kernels use them (a per-lane part + a part that is
 // the same in every lane).
 static int test_lf_layout()
 {
     int bad = 0;
-    for (int R : {64, 128, 256}) {
-        std::vector<char> seen((size_t)R * LF_C, 0);
+    const int shapes[5][2] = {{32, LF_C}, {64, LF_C}, {128, LF_C}, {256, LF_C}, {256, LF_C_BIG}};
+    for (auto &sh : shapes) {
+        const int R = sh[0], C = sh[1];
+        std::vector<char> seen((size_t)R * C, 0);
         for (int k1 = 0; k1 < R; k1++)
-            for (int c = 0; c < LF_C; c++) {
-                const int o = lf_row_off(k1) + lf_col_off(c);
-                if (o < 0 || o >= R * LF_C || seen[o]++) bad++;
+            for (int c = 0; c < C; c++) {
+                const int o = lf_row_off(k1, C) + lf_col_off(c);
+                if (o < 0 || o >= R * C || seen[o]++) bad++;
             }
+        const int ntf = R / 16;
+        for (int t = 0; t < 16; t++) {
+            for (int jp = 0; jp < 16 && jp + 16 * t < R; jp++)  // column passes' outputs: row jp + 16 t
+                if (lf_row_off(jp + 16 * t, C) != lf_row_off(16 * t, C) + jp * LF_CC) bad++;
+            for (int j = 0; j < ntf; j++)  // inverse column pass inputs: row j + t * R/16
+                if (lf_row_off(j + t * ntf, C) != lf_row_off(t * ntf, C) + j * LF_CC) bad++;
+            for (int ft = 0; ft < C / 16; ft++)  // row pass loads: point ft + (C/16) t
+                if (lf_col_off(ft + C / 16 * t) != lf_col_off(ft) + lf_col_off(C / 16 * t)) bad++;
+        }
+        for (int t = 0; t < C / 256; t++)
+            for (int jp = 0; jp < 256; jp++)  // row pass stores: point jp + 256 t
+                if (lf_col_off(jp + 256 * t) != lf_col_off(jp) + lf_col_off(256 * t)) bad++;
     }
-    for (int t = 0; t < 16; t++) {
-        for (int jp = 0; jp < 16; jp++)  // column passes' outputs and R = 256 inputs: row jp + 16 t
-            if (lf_row_off(jp + 16 * t) != lf_row_off(16 * t) + jp * LF_CC) bad++;
-        for (int ntf : {4, 8, 16})  // inverse column pass inputs: row j + t * R/16
-            for (int j = 0; j < ntf; j++)
-                if (lf_row_off(j + t * ntf) != lf_row_off(t * ntf) + j * LF_CC) bad++;
-        for (int ft = 0; ft < 128; ft++)  // row pass loads: point ft + 128 t
-            if (lf_col_off(ft + 128 * t) != lf_col_off(ft) + lf_col_off(128 * t)) bad++;
-    }
-    for (int t = 0; t < 8; t++)
-        for (int jp = 0; jp < 256; jp++)  // row pass stores: point jp + 256 t
-            if (lf_col_off(jp + 256 * t) != lf_col_off(jp) + lf_col_off(256 * t)) bad++;
     return bad;
 }
 
@@ -216,12 +219,19 @@ int main()
         printf("%-28s mismatches %d %s\n", "pad32 layout 2048", b, b == 0 ? "ok" : "FAIL");
         bad += b;
     }
+    {
+        const int b = test_pad32<4096>();
+        printf("%-28s mismatches %d %s\n", "pad32 layout 4096", b, b == 0 ? "ok" : "FAIL");
+        bad += b;
+    }
 #define CHECK(name, val, tol)                                  \
     do {                                                       \
         double e = (val);                                      \
         printf("%-28s rel err %.3e %s\n", name, e, e < tol ? "ok" : "FAIL"); \
         if (!(e < tol)) bad++;                                 \
     } while (0)
+    CHECK("fft 32 fwd", (test_fft<32, false>()), 2e-6);
+    CHECK("fft 32 inv", (test_fft<32, true>()), 2e-6);
     CHECK("fft 64 fwd", (test_fft<64, false>()), 2e-6);
     CHECK("fft 64 inv", (test_fft<64, true>()), 2e-6);
     CHECK("fft 128 fwd", (test_fft<128, false>()), 2e-6);   // the column transforms of the long-frame convolution

@@ -183,3 +183,37 @@ def test_power_of_two_gain_fold_is_one_rounding():
             ref = np.float32(np.float64(a) + np.float64(y) * np.float64(vol))
             one = np.float32(round_f32(Fraction(float(a)) + Fraction(float(y)) * Fraction(vol)))
             assert ref.tobytes() == one.tobytes() or (ref == 0 and one == 0), (a, y, vol, ref, one)
+
+
+def test_long_frame_cover_search_is_host_only_and_consistent():
+    """wp_lf_cover: the runs of equal frames that cover a result of L+M samples (no GPU needed).  Every run's
+    frames hold the whole impulse response, the runs' output ranges follow each other without gaps and reach
+    L+M, and the two bench workloads get the covers the design quotes."""
+    import ctypes as C
+    from dsp_amd import capi
+    lib = capi.lib()
+
+    def cover(L, M, nch):
+        r = (C.c_int64 * 12)()
+        n = lib.wp_lf_cover(L, M, nch, r)
+        assert 0 <= n <= 3
+        return [tuple(r[4 * i + k] for k in range(4)) for i in range(n)]
+
+    assert [(f, n) for f, n, _, _ in cover(2880000, 96000, 2)] == [(1048576, 3), (262144, 1)]
+    assert [(f, n) for f, n, _, _ in cover(2880000, 192000, 512)] == [(2097152, 1), (1048576, 1), (524288, 1)]
+    assert cover(44100, 22050, 1) == [] and cover(96000, 96000, 2) == []  # short inputs: partitioned form
+    lib.wp_tune(5, 2)  # long-frame wherever a cover exists
+    try:
+        for L, M, nch in [(600000, 5000, 2), (1150001, 96000, 2), (2880000, 96000, 2), (2880000, 192000, 512), (1000000, 800000, 2),
+                          (123457, 31, 1), (5000000, 700001, 3)]:
+            runs = cover(L, M, nch)
+            assert runs, (L, M)
+            base = 0
+            for frame, nfr, hop, first in runs:
+                assert frame in (1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21) and nfr >= 1
+                assert first == base and hop >= frame // 4 and frame - hop >= M - 1 and (frame - hop) % 64 == 0
+                base += nfr * hop
+            assert base >= L + M
+            assert [f for f, _, _, _ in runs] == sorted((f for f, _, _, _ in runs), reverse=True)
+    finally:
+        lib.wp_tune(5, 0)

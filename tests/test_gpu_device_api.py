@@ -443,30 +443,43 @@ def test_fused_paths_vs_oracle_all_plans(torch, oracle, L, M, tracks, per_track_
     assert torch.equal(bus.view(torch.int32), bus2.view(torch.int32))
 
 
-@pytest.mark.parametrize("L,M,tracks,cap,runs", [
-    (600000, 5000, 2, 0, [(262144, 3)]),                                   # three frames of 2^18
-    (1150001, 96000, 1, 1, [(524288, 3)]),                                 # one frame size only: 2^19; odd result length
-    (1300000, 96000, 1, 0, [(1048576, 1), (262144, 3)]),                   # a long frame, the rest in short ones
-    (1440000, 96000, 1, 0, [(1048576, 1), (524288, 1), (262144, 1)]),      # three frame sizes
-    (900000, 300000, 1, 0, [(1048576, 2)]),                                # M > 2^18: only 2^20 holds the kernel
+@pytest.mark.parametrize("L,M,tracks,cap,lim,runs", [
+    (600000, 5000, 2, 0, (18, 20), [(262144, 3)]),                                   # three frames of 2^18
+    (1150001, 96000, 1, 1, (18, 20), [(524288, 3)]),                                 # one frame size only: 2^19; odd result length
+    (1300000, 96000, 1, 0, (18, 20), [(1048576, 1), (262144, 3)]),                   # a long frame, the rest in short ones
+    (1440000, 96000, 1, 0, (18, 20), [(1048576, 1), (524288, 1), (262144, 1)]),      # three frame sizes
+    (900000, 300000, 1, 0, (18, 20), [(1048576, 2)]),                                # M > 2^18: only 2^20 holds the kernel
+    (600000, 5000, 2, 0, (0, 0), [(131072, 5)]),                                     # frames of 2^17 samples (32 rows)
+    (1300000, 96000, 1, 0, (0, 0), [(1048576, 1), (524288, 1), (131072, 1)]),        # the tail in one frame of 2^17
+    (2880000, 96000, 1, 0, (0, 0), [(1048576, 3), (262144, 1)]),                     # the 60 s render's cover with a shared stereo response
+    (2880000, 96000, 1, 0, (17, 21), [(2097152, 1), (1048576, 1), (131072, 1)]),     # its cover with the fewest frame samples: 2^21 (rows of 4096 points) + 2^20 + 2^17
+    (1000000, 800000, 1, 0, (0, 0), [(2097152, 2)]),                                 # M > 3/4 * 2^20: only 2^21 holds the kernel
 ])
-def test_long_frame_form_vs_oracle(torch, oracle, L, M, tracks, cap, runs):
+def test_long_frame_form_vs_oracle(torch, oracle, L, M, tracks, cap, lim, runs):
     """The long-frame form of the convolution (whole impulse response per frame, four-step transform)
     against the oracle: plain results with an odd output stride and a short input, the one-pass
     results + bus, the bus-only entry point, and the bus against wp_mix_dev of the written results
-    bit for bit.  A result is covered by up to three runs of equal frames (2^20, 2^19, 2^18 samples);
-    `cap` limits the number of runs (WP_TUNE_LF_RUNS)."""
+    bit for bit.  A result is covered by up to three runs of equal frames (2^21 ... 2^17 samples);
+    `cap` limits the number of runs (WP_TUNE_LF_RUNS), `lim` the frame sizes (2^lim[0] ... 2^lim[1])."""
     from dsp_amd import capi, device
     lib = capi.lib()
     njobs = 2 * tracks
     irs = np.stack([oracle.synth_ir(M, 800 + c) for c in range(2)])
     capi.check(lib.wp_tune(5, 2), "wp_tune")  # WP_TUNE_CONV_FORM: long-frame where the sizes allow
     capi.check(lib.wp_tune(6, cap), "wp_tune")  # WP_TUNE_LF_RUNS
+    capi.check(lib.wp_tune(10, lim[0]), "wp_tune")  # WP_TUNE_LF_MIN_FRAME
+    capi.check(lib.wp_tune(9, lim[1]), "wp_tune")  # WP_TUNE_LF_MAX_FRAME
+    capi.check(lib.wp_tune(11, 1 if lim == (17, 21) else 0), "wp_tune")  # WP_TUNE_LF_COST: 1 = bytes only
     try:
+        cover = (C.c_int64 * 12)()
+        assert lib.wp_lf_cover(L, M, 2, cover) == len(runs)
         ir = device.DeviceIR(torch.from_numpy(irs).cuda(), L)
     finally:
         lib.wp_tune(5, 0)
         lib.wp_tune(6, 0)
+        lib.wp_tune(9, 0)
+        lib.wp_tune(10, 0)
+        lib.wp_tune(11, 0)
     assert ir.info(9) == runs[0][0] and ir.info(10) == len(runs) and ir.info(11) == sum(f * n for f, n in runs)
     job_ch = [(j + 1) % 2 for j in range(njobs)]
     conv = device.BatchedConvolver(ir, job_ch)
@@ -526,24 +539,27 @@ def test_long_frame_form_vs_oracle(torch, oracle, L, M, tracks, cap, runs):
 
 
 @pytest.mark.parametrize("own_ir", [False, True])
-@pytest.mark.parametrize("L,M,frame0", [(300000, 3000, None), (1000000, 96000, 1048576)])
+@pytest.mark.parametrize("L,M,frame0", [(300000, 3000, None), (1000000, 96000, 1048576), (2100000, 96000, 2097152)])
 def test_long_frame_batch_row_pass_vs_oracle(torch, oracle, own_ir, L, M, frame0):
     """Batches of 16 jobs or more take the row pass that walks eight jobs per workgroup: 18 jobs (two full
     groups and a group of two) with a shared stereo impulse response (kernel spectra stored as product
     coefficients) and with an impulse response per job (plain spectra), every job against the oracle, the
     bus of the one-pass entry point against the oracle's mix of its own results, and the batch against
     one-job calls of the same handle bit for bit.  The second size is covered by a frame of 2^20 samples
-    (256 rows: the frame size of the 60 s render) and a frame of 2^18."""
+    (256 rows of 2048 points) and a frame of 2^18, the third by a frame of 2^21 samples (256 rows of 4096 points: the
+    largest frame of the 60 s render) and a shorter one."""
     from dsp_amd import capi, device
     lib = capi.lib()
     njobs = 18
     nir = njobs if own_ir else 2
     irs = np.stack([oracle.synth_ir(M, 700 + c) for c in range(nir)])
     capi.check(lib.wp_tune(5, 2), "wp_tune")  # long-frame form
+    capi.check(lib.wp_tune(11, 1), "wp_tune")  # cover with the fewest frame samples, whatever the row length
     try:
         ir = device.DeviceIR(torch.from_numpy(irs).cuda(), L)
     finally:
         lib.wp_tune(5, 0)
+        lib.wp_tune(11, 0)
     assert ir.info(10) >= 1
     job_ch = list(range(njobs)) if own_ir else [j % 2 for j in range(njobs)]
     conv = device.BatchedConvolver(ir, job_ch)

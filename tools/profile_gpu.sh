@@ -12,6 +12,7 @@ ARGS="--steps 4 --warmup 2 --no-cpu-baseline --no-fused-extra --no-verify $*"
 PARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-fused-extra --no-verify $*"
 run() { name=$1; shift; echo "== $name"; timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" $BARGS > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }; }
 BARGS=$ARGS  run stats --kernel-trace --stats || exit 1
+if [ "${PROF_ONLY:-}" = "stats" ]; then python3 "$ROOT/tools/summarize_prof.py" "$OUT" | tee "$OUT/summary.txt"; exit 0; fi  # kernel trace only
 BARGS=$PARGS run pmc_fetch --pmc FETCH_SIZE || exit 1
 BARGS=$PARGS run pmc_write --pmc WRITE_SIZE || exit 1
 BARGS=$PARGS run pmc_sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY || exit 1
