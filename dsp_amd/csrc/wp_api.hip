@@ -1563,26 +1563,10 @@ static int mix_scratch(int dev, size_t bytes, hipStream_t s, Scratch **out)
     return WP_OK;
 }
 
-extern "C" int wp_mix_dev(float *const *tgt_dev, int tch, int64_t tl, const wp_src *srcs, int64_t nsrc,
-                          int srcs_on_device, void *stream)
+// sources [0, nsrc) none of which overlaps the target: one pass of the tiled kernel
+static int mix_dev_run(float *const *tgt_dev, int tch, int64_t tl, const wp_src *srcs, int64_t nsrc, int srcs_on_device, hipStream_t s)
 {
-    if (int rc = need_device()) return rc;
-    if (!tgt_dev || tl < 0 || nsrc < 0 || (nsrc > 0 && !srcs)) return fail(WP_ERR_INVALID, "wp_mix_dev: bad argument");
-    if (tch < 1 || !tgt_dev[0] || (tch >= 2 && !tgt_dev[1])) return fail(WP_ERR_INVALID, "wp_mix_dev: null target channel");
-    if (nsrc == 0 || tl == 0) return WP_OK;
-    if (!srcs_on_device) {
-        // the kernel updates the target in place while other lanes read the sources: a source
-        // that overlaps the target (a feedback mix in the reference) would race
-        for (int64_t i = 0; i < nsrc; i++) {
-            const wp_src &S = srcs[i];
-            if (S.nch != 1 && S.nch != 2) continue;
-            for (int c = 0; c < S.nch; c++)
-                for (int t = 0; t < tch && t < 2; t++)
-                    if (S.ch[c] && S.ch[c] < tgt_dev[t] + tl && tgt_dev[t] < S.ch[c] + S.rl)
-                        return fail(WP_ERR_UNSUPPORTED, "wp_mix_dev: source %lld overlaps the target in device memory; not implemented", (long long)i);
-        }
-    }
-    hipStream_t s = (hipStream_t)stream;
+    if (nsrc == 0) return WP_OK;
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     const size_t src_bytes = (sizeof(wp_src) * (size_t)nsrc + 255) & ~(size_t)255;
@@ -1604,86 +1588,157 @@ extern "C" int wp_mix_dev(float *const *tgt_dev, int tch, int64_t tl, const wp_s
     return WP_OK;
 }
 
+// does a channel of the source share memory with the part of the target the call updates?
+static bool src_overlaps_target(const wp_src &S, float *const *tgt, int tch, int64_t tl)
+{
+    if (S.nch != 1 && S.nch != 2) return false;
+    for (int c = 0; c < S.nch; c++)
+        for (int t = 0; t < tch && t < 2; t++)
+            if (S.ch[c] && S.rl > 0 && S.ch[c] < tgt[t] + tl && tgt[t] < S.ch[c] + S.rl) return true;
+    return false;
+}
+
+extern "C" int wp_mix_dev(float *const *tgt_dev, int tch, int64_t tl, const wp_src *srcs, int64_t nsrc,
+                          int srcs_on_device, void *stream)
+{
+    if (int rc = need_device()) return rc;
+    if (!tgt_dev || tl < 0 || nsrc < 0 || (nsrc > 0 && !srcs)) return fail(WP_ERR_INVALID, "wp_mix_dev: bad argument");
+    if (tch < 1 || !tgt_dev[0] || (tch >= 2 && !tgt_dev[1])) return fail(WP_ERR_INVALID, "wp_mix_dev: null target channel");
+    if (nsrc == 0 || tl == 0) return WP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (srcs_on_device) return mix_dev_run(tgt_dev, tch, tl, srcs, nsrc, 1, s);  // (a table on the device is taken as free of overlaps)
+    // The tiled kernel updates the target while other lanes read the sources, so a source that overlaps the
+    // target (mixBuffers(t, a, t), a feedback mix) cannot ride in it: the reference reads it sample by sample
+    // as the loop goes (src/mix-buffers.js:4, 20-67).  The source list is cut at such sources: the runs
+    // between them take the tiled kernel, each of them the frame-by-frame one, all in source order.
+    int64_t from = 0;
+    for (int64_t i = 0; i < nsrc; i++) {
+        if (!src_overlaps_target(srcs[i], tgt_dev, tch, tl)) continue;
+        if (int rc = mix_dev_run(tgt_dev, tch, tl, srcs + from, i - from, 0, s)) return rc;
+        if (tch <= 2) HIPCHK(launch_mix_serial(tgt_dev[0], tch >= 2 ? tgt_dev[1] : nullptr, tch, tl, srcs[i], s));
+        from = i + 1;
+    }
+    return mix_dev_run(tgt_dev, tch, tl, srcs + from, nsrc - from, 0, s);
+}
+
 extern "C" int wp_mix(float *const *tgt, int tch, int64_t tl, const wp_src *srcs, int64_t nsrc)
 {
     if (int rc = need_device()) return rc;
     if (!tgt || tl < 0 || nsrc < 0 || (nsrc > 0 && !srcs)) return fail(WP_ERR_INVALID, "wp_mix: bad argument");
     if (tch < 1 || !tgt[0] || (tch >= 2 && !tgt[1])) return fail(WP_ERR_INVALID, "wp_mix: null target channel");
     if (nsrc == 0 || tl == 0 || tch > 2) return WP_OK;
-    // stage every distinct host array once
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    std::map<std::pair<const void *, size_t>, size_t> where;  // (host ptr, bytes) -> offset
-    size_t total = 0;
-    auto place = [&](const void *p, size_t bytes) {
-        auto key = std::make_pair(p, bytes);
-        auto it = where.find(key);
-        if (it == where.end()) {
-            where[key] = total;
-            total += al(bytes);
-        }
+    // Host arrays that share memory must share it on the device too (a source that is the target itself, or a
+    // view into it, is read as the loop updates it: src/mix-buffers.js:4).  Every target channel starts an
+    // arena = a range of host memory staged as one piece; a source channel that overlaps an arena joins it
+    // (the arena grows to hold both).  Everything else is staged once per distinct array.
+    struct Arena {
+        const char *lo, *hi;
+        size_t off;
     };
-    // the target gets a staging copy of its own: a source that is the very same host array
-    // (mixBuffers(t, t)) is then read as it was before the call instead of overlapping the
-    // range the kernel updates in place
-    size_t tgt_off[2] = {0, 0};
-    for (int c = 0; c < tch; c++) {
-        tgt_off[c] = total;
-        total += al(sizeof(float) * (size_t)tl);
-    }
+    std::vector<Arena> arenas;
+    for (int c = 0; c < tch; c++)
+        arenas.push_back({reinterpret_cast<const char *>(tgt[c]), reinterpret_cast<const char *>(tgt[c] + tl), 0});
     for (int64_t i = 0; i < nsrc; i++) {
         const wp_src &S = srcs[i];
         if (S.nch != 1 && S.nch != 2) continue;
         if (S.rl < 0) return fail(WP_ERR_INVALID, "wp_mix: source %lld has negative length", (long long)i);
-        for (int c = 0; c < S.nch; c++) {
+        for (int c = 0; c < S.nch; c++)
             if (!S.ch[c] && S.rl > 0) return fail(WP_ERR_INVALID, "wp_mix: source %lld channel %d is null", (long long)i, c);
-            place(S.ch[c], sizeof(float) * (size_t)S.rl);
+    }
+    for (bool grown = true; grown;) {  // until no source channel straddles an arena's edge
+        grown = false;
+        for (int64_t i = 0; i < nsrc; i++) {
+            const wp_src &S = srcs[i];
+            if (S.nch != 1 && S.nch != 2) continue;
+            for (int c = 0; c < S.nch; c++) {
+                const char *lo = reinterpret_cast<const char *>(S.ch[c]), *hi = reinterpret_cast<const char *>(S.ch[c] + S.rl);
+                for (Arena &A : arenas)
+                    if (lo < A.hi && A.lo < hi && (lo < A.lo || hi > A.hi)) {
+                        if (lo < A.lo) A.lo = lo;
+                        if (hi > A.hi) A.hi = hi;
+                        grown = true;
+                    }
+            }
         }
+        for (size_t a = 0; a + 1 < arenas.size(); a++)  // two arenas that have come to overlap become one
+            for (size_t b = a + 1; b < arenas.size(); b++)
+                if (arenas[a].lo < arenas[b].hi && arenas[b].lo < arenas[a].hi) {
+                    if (arenas[b].lo < arenas[a].lo) arenas[a].lo = arenas[b].lo;
+                    if (arenas[b].hi > arenas[a].hi) arenas[a].hi = arenas[b].hi;
+                    arenas.erase(arenas.begin() + (long)b);
+                    b--;
+                    grown = true;
+                }
+    }
+    size_t total = 0;
+    for (Arena &A : arenas) {
+        A.off = total + (reinterpret_cast<uintptr_t>(A.lo) & 255);  // keeps the arrays' alignment within 256 bytes
+        total += al((size_t)(A.hi - A.lo) + 256);
+    }
+    auto in_arena = [&](const void *p, size_t bytes) -> const Arena * {
+        const char *lo = reinterpret_cast<const char *>(p);
+        for (const Arena &A : arenas)
+            if (bytes > 0 && lo >= A.lo && lo + bytes <= A.hi) return &A;
+        return nullptr;
+    };
+    std::map<std::pair<const void *, size_t>, size_t> where;  // (host ptr, bytes) -> offset, arrays outside the arenas
+    auto place = [&](const void *p, size_t bytes) {
+        if (in_arena(p, bytes)) return;
+        auto key = std::make_pair(p, bytes);
+        if (where.find(key) == where.end()) {
+            where[key] = total;
+            total += al(bytes);
+        }
+    };
+    for (int64_t i = 0; i < nsrc; i++) {
+        const wp_src &S = srcs[i];
+        if (S.nch != 1 && S.nch != 2) continue;
+        for (int c = 0; c < S.nch; c++) place(S.ch[c], sizeof(float) * (size_t)S.rl);
         if (S.vol_vec) place(S.vol_vec, sizeof(double) * (size_t)tl);
     }
-    // grow-only staging area, one per calling thread: repeated mixBuffers calls (one per bar in
+    // grow-only staging area, one per calling thread and device: repeated mixBuffers calls (one per bar in
     // the reference's render loop) do not pay for hipMalloc/hipFree each time
-    static thread_local struct Stage {
+    struct Stage {
         char *p = nullptr;
         size_t cap = 0;
-        int dev = -1;  // released with the process (no destructor: the HIP runtime may already be gone)
-    } stage;
+    };
+    static thread_local std::map<int, Stage> stages;  // released with the process (the HIP runtime may be gone before a destructor runs)
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
-    if (stage.cap < total || stage.dev != dev) {
+    Stage &stage = stages[dev];
+    if (stage.cap < total) {
         if (stage.p) (void)hipFree(stage.p);
         stage.p = nullptr;
         stage.cap = 0;
         const size_t cap = total < (1 << 20) ? (1 << 20) : total + total / 4;
         HIPCHK(hipMalloc((void **)&stage.p, cap));
         stage.cap = cap;
-        stage.dev = dev;
     }
     char *d = stage.p;
-    int rc = WP_OK;
-    for (int c = 0; c < tch; c++) {
-        hipError_t e = hipMemcpy(d + tgt_off[c], tgt[c], sizeof(float) * (size_t)tl, hipMemcpyHostToDevice);
+    for (const Arena &A : arenas) {
+        hipError_t e = hipMemcpy(d + A.off, A.lo, (size_t)(A.hi - A.lo), hipMemcpyHostToDevice);
         if (e != hipSuccess) return fail(WP_ERR_HIP, "hipMemcpy(H2D) failed: %s", hipGetErrorString(e));
     }
     for (auto &kv : where) {
         if (kv.first.second == 0) continue;
         hipError_t e = hipMemcpy(d + kv.second, kv.first.first, kv.first.second, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            return fail(WP_ERR_HIP, "hipMemcpy(H2D) failed: %s", hipGetErrorString(e));
-        }
+        if (e != hipSuccess) return fail(WP_ERR_HIP, "hipMemcpy(H2D) failed: %s", hipGetErrorString(e));
     }
+    auto dev_of = [&](const void *p, size_t bytes) -> char * {
+        if (const Arena *A = in_arena(p, bytes)) return d + A->off + (reinterpret_cast<const char *>(p) - A->lo);
+        return d + where[std::make_pair(p, bytes)];
+    };
     std::vector<wp_src> ds(srcs, srcs + nsrc);
     for (int64_t i = 0; i < nsrc; i++) {
         wp_src &S = ds[i];
         if (S.nch != 1 && S.nch != 2) continue;
-        for (int c = 0; c < S.nch; c++)
-            S.ch[c] = reinterpret_cast<const float *>(d + where[std::make_pair((const void *)srcs[i].ch[c], sizeof(float) * (size_t)S.rl)]);
-        if (S.vol_vec)
-            S.vol_vec = reinterpret_cast<const double *>(d + where[std::make_pair((const void *)srcs[i].vol_vec, sizeof(double) * (size_t)tl)]);
+        for (int c = 0; c < S.nch; c++) S.ch[c] = reinterpret_cast<const float *>(dev_of(srcs[i].ch[c], sizeof(float) * (size_t)S.rl));
+        if (S.vol_vec) S.vol_vec = reinterpret_cast<const double *>(dev_of(srcs[i].vol_vec, sizeof(double) * (size_t)tl));
     }
     float *td[2] = {nullptr, nullptr};
-    for (int c = 0; c < tch; c++)
-        td[c] = reinterpret_cast<float *>(d + tgt_off[c]);
-    rc = wp_mix_dev(td, tch, tl, ds.data(), nsrc, 0, nullptr);
+    for (int c = 0; c < tch; c++) td[c] = reinterpret_cast<float *>(dev_of(tgt[c], sizeof(float) * (size_t)tl));
+    int rc = wp_mix_dev(td, tch, tl, ds.data(), nsrc, 0, nullptr);
     if (rc == WP_OK) {
         for (int c = 0; c < tch && rc == WP_OK; c++) {
             hipError_t e = hipMemcpy(tgt[c], td[c], sizeof(float) * (size_t)tl, hipMemcpyDeviceToHost);
@@ -1872,27 +1927,37 @@ extern "C" int wp_buf_copy(wp_buf *dst, int dch, int64_t dst_off, const wp_buf *
         // TypedArray.set copies as if through a temporary when the ranges overlap.  The temporary
         // is a grow-only area per calling thread and device; a later overlapping copy waits for
         // the one before it (an event, not a stream synchronisation) before it reuses the area.
-        static thread_local struct Tmp {
+        struct Tmp {
             float *p = nullptr;
             size_t cap = 0;
-            int dev = -1;
             hipEvent_t ev = nullptr;
             bool pending = false;
-        } tmp;
+        };
+        static thread_local std::map<int, Tmp> tmps;  // one per device the thread copies on; released with the process
+        Tmp &tmp = tmps[dst->dev];
         const size_t bytes = sizeof(float) * (size_t)n;
         if (tmp.pending) {
             HIPCHK(hipEventSynchronize(tmp.ev));
             tmp.pending = false;
         }
-        if (tmp.cap < bytes || tmp.dev != dst->dev) {
-            if (tmp.p) (void)hipFree(tmp.p);
-            tmp.p = nullptr;
-            tmp.cap = 0;
-            HIPCHK(hipMalloc((void **)&tmp.p, bytes < (1 << 20) ? (1 << 20) : bytes));
-            tmp.cap = bytes < (1 << 20) ? (1 << 20) : bytes;
-            tmp.dev = dst->dev;
+        if (tmp.cap < bytes || !tmp.ev) {
+            // the area and its event belong to the buffers' device, whichever device is current
+            int cur = 0;
+            HIPCHK(hipGetDevice(&cur));
+            if (cur != dst->dev) HIPCHK(hipSetDevice(dst->dev));
+            hipError_t e = hipSuccess;
+            if (tmp.cap < bytes) {
+                if (tmp.p) (void)hipFree(tmp.p);
+                tmp.p = nullptr;
+                tmp.cap = 0;
+                const size_t cap = bytes < (1 << 20) ? (1 << 20) : bytes;
+                e = hipMalloc((void **)&tmp.p, cap);
+                if (e == hipSuccess) tmp.cap = cap;
+            }
+            if (e == hipSuccess && !tmp.ev) e = hipEventCreateWithFlags(&tmp.ev, hipEventDisableTiming);
+            if (cur != dst->dev) (void)hipSetDevice(cur);
+            HIPCHK(e);
         }
-        if (!tmp.ev) HIPCHK(hipEventCreateWithFlags(&tmp.ev, hipEventDisableTiming));
         HIPCHK(hipMemcpyAsync(tmp.p, s, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
         HIPCHK(hipMemcpyAsync(d, tmp.p, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
         HIPCHK(hipEventRecord(tmp.ev, (hipStream_t)stream));

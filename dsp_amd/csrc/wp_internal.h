@@ -81,6 +81,8 @@ hipError_t launch_add_prev(float *out, int64_t out_stride, const float *prev, in
 size_t mix_scratch_bytes(int64_t nsrc);  // bytes of device scratch launch_mix needs
 hipError_t launch_mix(float *t0, float *t1, int tch, int64_t tl, const wp_src *srcs_dev, void *scratch,
                       int64_t nsrc, hipStream_t s);
+// one source that overlaps the target in memory, frame by frame in the reference's order (device pointers in `src`)
+hipError_t launch_mix_serial(float *t0, float *t1, int tch, int64_t tl, const wp_src &src, hipStream_t s);
 hipError_t launch_synth_noise(float *out, int64_t n, uint32_t seed, int64_t start, hipStream_t s);
 
 }  // namespace wp

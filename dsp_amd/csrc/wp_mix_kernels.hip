@@ -341,6 +341,56 @@ hipError_t launch_mix(float *t0, float *t1, int tch, int64_t tl, const wp_src *s
 }
 
 // ---------------------------------------------------------------------------
+// One source whose samples overlap the target in memory (mixBuffers(t, a, t), a feedback mix
+// mixBuffers(t, [t, 1, g, -k]) ...): src/mix-buffers.js:20-67 reads and writes sample by sample, so a read
+// may see what earlier iterations of the same loop wrote.  One lane walks the frames in the reference's
+// order with every access going to memory: exact for any overlap, and as slow as that sounds (about a
+// microsecond per frame); the tiled kernel above takes every source that does not overlap the target.
+template <int TCH>
+__global__ void k_mix_serial(volatile float *t0, volatile float *t1, int64_t tl, wp_src S)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t asl = S.sl < 0 ? -S.sl : S.sl;
+    const volatile float *c0 = S.ch[0], *c1 = S.nch == 2 ? S.ch[1] : S.ch[0];
+    const volatile double *vv = S.vol_vec;
+    const bool nan_all = asl == 0 || S.rl <= 0;  // x % 0 is NaN -> undefined -> NaN
+    const double nanv = (double)__builtin_nanf("");
+    for (int64_t x = 0; x < tl; x++) {
+        int64_t i = -1;  // -1: the reference reads `undefined` (NaN)
+        if (!nan_all) {
+            const int64_t a = x + S.o;
+            const int64_t r = (a % asl) % S.rl;  // C++ and JavaScript remainders both take the dividend's sign
+            i = a >= 0 ? r : (r == 0 ? 0 : -1);  // -0 names element 0
+        }
+        const double vol = vv ? vv[x] : S.vol;
+        if (TCH == 2) {
+            if (S.nch == 2) {
+                t0[x] = (float)((double)t0[x] + (i < 0 ? nanv : (double)c0[i]) * vol);
+                t1[x] = (float)((double)t1[x] + (i < 0 ? nanv : (double)c1[i]) * vol);
+            } else {
+                t0[x] = (float)((double)t0[x] + ((i < 0 ? nanv : (double)c0[i]) / 2.0) * vol);
+                t1[x] = (float)((double)t1[x] + ((i < 0 ? nanv : (double)c0[i]) / 2.0) * vol);
+            }
+        } else {
+            if (S.nch == 2)
+                t0[x] = (float)((double)t0[x] + (((i < 0 ? nanv : (double)c0[i]) + (i < 0 ? nanv : (double)c1[i])) / 2.0) * vol);
+            else
+                t0[x] = (float)((double)t0[x] + (i < 0 ? nanv : (double)c0[i]) * vol);
+        }
+    }
+}
+
+hipError_t launch_mix_serial(float *t0, float *t1, int tch, int64_t tl, const wp_src &src, hipStream_t s)
+{
+    if (tl <= 0 || (tch != 1 && tch != 2) || (src.nch != 1 && src.nch != 2)) return hipSuccess;
+    if (tch == 2)
+        hipLaunchKernelGGL((k_mix_serial<2>), dim3(1), dim3(64), 0, s, t0, t1, tl, src);
+    else
+        hipLaunchKernelGGL((k_mix_serial<1>), dim3(1), dim3(64), 0, s, t0, t1, tl, src);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // synthetic noise: murmur3 finaliser over the sample index, 24-bit mantissa
 __global__ void k_synth_noise(float *__restrict__ out, int64_t n, uint32_t k, int64_t start)
 {

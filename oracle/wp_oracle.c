@@ -327,9 +327,9 @@ int wpo_mix_source(float *const *tgt, int tch, int64_t tl, const float *const *s
     } else if (tch == 2 && sch == 1) {                       /* :25-30, :53-57 */
         for (int64_t x = 0; x < tl; x++) {
             const double v = vol_vec ? vol_vec[x] : vol;
-            const double s = src_at(src[0], x, o, sl, rl);
-            tgt[0][x] = (float)((double)tgt[0][x] + (s / 2.0) * v);
-            tgt[1][x] = (float)((double)tgt[1][x] + (s / 2.0) * v);
+            /* two reads, as in the reference: a source that shares memory with target[0] is read again after the first store */
+            tgt[0][x] = (float)((double)tgt[0][x] + (src_at(src[0], x, o, sl, rl) / 2.0) * v);
+            tgt[1][x] = (float)((double)tgt[1][x] + (src_at(src[0], x, o, sl, rl) / 2.0) * v);
         }
     } else if (tch == 1 && sch == 2) {                       /* :33-37, :60-63 */
         for (int64_t x = 0; x < tl; x++) {

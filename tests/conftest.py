@@ -58,3 +58,23 @@ def oracle():
     from oracle import oracle as o
     o.build()
     return o
+
+
+def shared_memory_mix_case(case):
+    """A g11 case rebuilt with the same memory sharing: (base arrays, target channel views, sources) where
+    every channel is a numpy view [begin, end) into one of the bases."""
+    vol_fns = {"ramp": lambda x: 0.25 + x / 8, "alt": lambda x: -1.3 if (x & 1) else 0.7}
+    bases = [from_bits(b).copy() for b in case["bases_in"]]
+    view = lambda spec: bases[spec[0]][spec[1]:spec[2]]  # noqa: E731
+    target = [view(t) for t in case["target"]]
+    sources = []
+    for s in case["sources"]:
+        ch = [view(c) for c in s["ch"]]
+        if "length" not in s:
+            sources.append(ch)
+            continue
+        vol = s.get("volume")
+        if isinstance(vol, dict):
+            vol = vol_fns[vol["fn"]]
+        sources.append((ch, s["length"], vol, s.get("offset")))
+    return bases, target, sources

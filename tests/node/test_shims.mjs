@@ -116,6 +116,22 @@ const main = async () => {
     c.target_out.forEach((exp, ch) => same(target[ch], exp, c.name + ' ch' + ch))
   }
 
+  // G11: sources that share memory with the target (the same arrays, views into and beyond them), bit-exact
+  // over everything the call may touch
+  for (const c of golden('g11_mix_shared_memory.json').cases) {
+    const bases = c.bases_in.map(f32)
+    const view = spec => bases[spec[0]].subarray(spec[1], spec[2])
+    const target = c.target.map(view)
+    const sources = c.sources.map(s => {
+      const ch = s.ch.map(view)
+      if (!('length' in s)) return ch
+      return [ch, s.length, (typeof s.volume === 'object') ? vols[s.volume.fn] : s.volume, s.offset]
+    })
+    if (mixBuffers(target, ...sources) !== target) fail('mixBuffers must return target')
+    c.bases_out.forEach((exp, i) => same(bases[i], exp, c.name + ' base ' + i))
+    checks++
+  }
+
   // C1 through the wrapper
   {
     const g = golden('g5_config_sized.json').c1

@@ -835,3 +835,44 @@ def test_bench_path_full_length_against_reference_golden(torch):
         for t in range(tracks):
             acc = (acc.astype(np.float64) + o[2 * t + ch, sl].astype(np.float64) * vol[t]).astype(np.float32)
         assert np.array_equal(acc, bus[ch, sl].cpu().numpy())
+
+
+def test_two_host_threads_drive_two_plans_of_one_ir(torch, oracle):
+    """What two Node workers do after receiving the same kernel object: two host threads, each with a plan
+    (wp_conv) of its own made from ONE wp_ir, each on a stream of its own, run at the same time (ctypes
+    releases the interpreter lock during the calls).  Every result equals the one computed alone."""
+    import threading
+    from dsp_amd import device
+    L, M = 40000, 9000
+    irs = np.stack([oracle.synth_ir(M, 31), oracle.synth_ir(M, 32)])
+    ir = device.DeviceIR(torch.from_numpy(irs).cuda(), L)
+    x = torch.from_numpy(np.stack([oracle.synth_noise(L, 40 + j) for j in range(4)])).cuda()
+    alone = torch.empty((4, L + M), dtype=torch.float32, device="cuda")
+    device.BatchedConvolver(ir, [0, 1, 0, 1]).run(x, alone)
+    torch.cuda.synchronize()
+    want = oracle.fft_convolution(L, oracle.fft_process_kernel(L, irs[1]), M)(x[3].cpu().numpy())
+    assert float(np.abs(alone[3].cpu().numpy().astype(np.float64) - want).max()) <= TOL
+    errors = []
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            conv = device.BatchedConvolver(ir, [0, 1])
+            out = torch.empty((2, L + M), dtype=torch.float32, device="cuda")
+            with torch.cuda.stream(stream):
+                for _ in range(20):
+                    out.zero_()
+                    conv.run(x[2 * k:2 * k + 2], out)
+                stream.synchronize()
+            if not torch.equal(out.view(torch.int32), alone[2 * k:2 * k + 2].view(torch.int32)):
+                errors.append("thread %d: results differ from the single-threaded run" % k)
+        except Exception as e:  # noqa: BLE001
+            errors.append("thread %d: %r" % (k, e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors

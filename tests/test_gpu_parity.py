@@ -331,6 +331,20 @@ def test_g8_mix_negative_offsets_bit_exact(wp):
             assert_bits_equal(target[ch], exp, case["name"] + " ch%d" % ch)
 
 
+def test_g11_mix_sources_that_share_memory_with_the_target_bit_exact(wp):
+    """Sources that are the target itself, views into it, or views that reach beyond it: the host-array entry
+    point keeps the sharing on the device (one staged piece per group of overlapping arrays) and such sources
+    are folded frame by frame in the reference's order; everything the call may touch is compared."""
+    from conftest import shared_memory_mix_case
+    g = load_golden("g11_mix_shared_memory.json")
+    for case in g["cases"]:
+        bases, target, sources = shared_memory_mix_case(case)
+        ret = wp.mix.mix_buffers(target, *sources)
+        assert ret is target
+        for i, exp in enumerate(case["bases_out"]):
+            assert_bits_equal(bases[i], exp, case["name"] + " base %d" % i)
+
+
 def test_g9_render_buffer_conventions_host_and_device(wp):
     """The buffer conventions of src/render.js:27-48 reproduced by the mix kernel, with host
     arrays (wp_mix) and with device-resident buffers (wp_buf + wp_mix_dev, the route a bar

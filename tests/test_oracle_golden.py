@@ -222,6 +222,19 @@ def test_g8_mix_negative_offsets(oracle):
     assert np.isnan(first).any() and np.isfinite(first).any()
 
 
+def test_g11_mix_sources_that_share_memory_with_the_target(oracle):
+    """mixBuffers(t, a, t), feedback offsets, views into and beyond the target: the reference reads such a
+    source sample by sample as the loop updates the target (src/mix-buffers.js:4, 20-67)."""
+    from conftest import shared_memory_mix_case
+    g = load_golden("g11_mix_shared_memory.json")
+    assert len(g["cases"]) == 15
+    for case in g["cases"]:
+        bases, target, sources = shared_memory_mix_case(case)
+        oracle.mix_buffers(target, *sources)
+        for i, exp in enumerate(case["bases_out"]):
+            assert_bits_equal(bases[i], exp, case["name"] + " base %d" % i)
+
+
 def render_conventions_via_mix(mix_buffers, g):
     """src/render.js:27-48 as mixBuffers arithmetic on a zeroed buffer: a mono function's
     samples into 2 channels are (s/2)*1 on both (render: /numOfChannels, then buffer[1].set(buffer[0])),
