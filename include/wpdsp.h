@@ -233,13 +233,18 @@ typedef struct wp_src {
 } wp_src;
 /* src/mix-buffers.js:7: sl = (rl*length)|0 with JavaScript ToInt32 semantics. */
 int32_t wp_mix_sl(int64_t rl, double length);
-/* Host buffers: tgt[0..tch) of tl floats are updated in place. */
+/* Host buffers: tgt[0..tch) of tl floats are updated in place.  Arrays that share
+ * memory (a source that is the target itself, a view into it or one that reaches beyond
+ * it) share it on the device too, and such a source is read sample by sample as the loop
+ * updates the target, like the reference's (src/mix-buffers.js:4, 20-67: mixBuffers(t, a, t)
+ * leaves 2(t+a)). */
 int wp_mix(float *const *tgt, int tch, int64_t tl, const wp_src *srcs, int64_t nsrc);
 /* Device buffers: every pointer inside tgt_dev/srcs is a device pointer; the
  * srcs array itself is in host memory unless srcs_on_device != 0.  The target is
- * updated in place, so a source must not overlap it (WP_ERR_UNSUPPORTED when the
- * srcs array is in host memory and shows an overlap; wp_mix, which stages host
- * arrays, reads an aliased source as it was before the call). */
+ * updated in place.  A source that overlaps it in memory is folded frame by frame in
+ * the reference's order by one lane (exact for any overlap, about a microsecond per
+ * frame); the sources before and after it take the tiled kernel.  A source table
+ * that lives on the device is taken to be free of overlaps. */
 int wp_mix_dev(float *const *tgt_dev, int tch, int64_t tl, const wp_src *srcs, int64_t nsrc, int srcs_on_device,
                void *stream);
 

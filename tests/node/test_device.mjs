@@ -90,10 +90,20 @@ const main = async () => {
     }
   }
 
-  // ---- refused rather than undefined: a source that overlaps the device bus, ragged channels
+  // ---- a source that shares memory with the device bus is read as the loop updates the bus, like the reference's
+  // arrays (src/mix-buffers.js:4): the same calls on host arrays (pinned to the reference's vectors) give the same bits
+  {
+    const host = [ramp(100, 31), ramp(100, 32)], other = [ramp(100, 33), ramp(100, 34)]
+    const dev = DeviceBuffer.upload(host.map(a => Float32Array.from(a)))
+    mixBuffers(dev, dev, Array.from(DeviceBuffer.upload(other)), [dev, 1, 0.5, 7])
+    mixBuffers(host, host, other, [host, 1, 0.5, 7])
+    host.forEach((a, c) => sameBits(dev[c], a, 'device bus mixed with itself ch' + c))
+    checks++
+  }
+
+  // ---- refused rather than undefined: ragged channels
   {
     const bus = DeviceBuffer.alloc(2, 100)
-    try { mixBuffers(bus, bus); fail('aliased device mix accepted') } catch (e) { if (!/overlaps the target/.test(e.message)) throw e; checks++ }
     const ragged = [DeviceBuffer.alloc(1, 100)[0], DeviceBuffer.alloc(1, 50)[0]]
     try { mixBuffers(bus, ragged); fail('ragged device source accepted') } catch (e) { if (!(e instanceof TypeError)) throw e; checks++ }
     try { mixBuffers([new Float32Array(100), new Float32Array(100)], [new Float32Array(100), new Float32Array(50)]); fail('ragged host source accepted') } catch (e) { if (!(e instanceof TypeError)) throw e; checks++ }
