@@ -52,6 +52,7 @@ def parse():
                          "kernel); twopass: wp_conv_run_dev then wp_mix_dev; fused: wp_conv_mix_run_dev (bus only, "
                          "per-track results never written).  All three give the same bus, bit for bit.")
     ap.add_argument("--no-fused-extra", action="store_true", help="skip the extra fused-path measurement")
+    ap.add_argument("--no-partitioned-extra", action="store_true", help="skip the extra measurement of the partitioned form")
     ap.add_argument("--no-c5-extra", action="store_true", help="with --gpus > 1: skip the extra 4 s-IR measurement")
     ap.add_argument("--reduce", choices=["capi", "torch"], default="capi",
                     help="capi: wp_bus_reduce (RCCL through the C ABI; rendezvous over gloo); torch: torch.distributed's "
@@ -426,6 +427,47 @@ def main():
                        "note": "wp_conv_mix_run_dev: identical bus, per-track results and the M-sample tails beyond the "
                                "bus are not produced, so it is reported beside the headline, not as it"}
 
+    # secondary measurement: the same workload forced onto the partitioned form (forward transforms, multiply-accumulate
+    # over the impulse response's partitions, inverse transforms: the algorithm the metric's name describes), so that it
+    # has a number from the same run beside the form the library picks
+    part_extra = None
+    if onepass and lf and not a.no_partitioned_extra:
+        import numpy as np
+        capi.check(capi.lib().wp_tune(5, 1), "wp_tune")  # WP_TUNE_CONV_FORM: partitioned
+        try:
+            if a.config == "c3":
+                irp = dev.DeviceIR(torch.from_numpy(np.stack([dev.synth_ir(M, 500000), dev.synth_ir(M, 500001)])).cuda().contiguous(), F)
+                convp = dev.BatchedConvolver(irp, [j % 2 for j in range(njobs)])
+            else:
+                irp = dev.DeviceIR(torch.from_numpy(np.stack([dev.synth_ir(M, 500000 + 2 * (w.t_lo + j // 2) + (j % 2))
+                                                              for j in range(njobs)])).cuda().contiguous(), F)
+                convp = dev.BatchedConvolver(irp, list(range(njobs)))
+        finally:
+            capi.lib().wp_tune(5, 0)
+        convp.profile(True)
+        pk = [0.0, 0.0, 0.0]
+
+        def stepp(timed):
+            buses[0].zero_()
+            convp.run_and_mix(x, out, [buses[0][0], buses[0][1]], vol)
+            if timed:
+                for i, v in enumerate(convp.profile_read()):
+                    pk[i] += v
+        pdt = time_steps(stepp, 1, a.steps)
+        Bp, Tp = int(capi.lib().wp_conv_info(convp.handle, 2)), int(capi.lib().wp_conv_info(convp.handle, 1))
+        Tinp = min(Tp, (F + Bp - 1) // Bp + 1)
+        mac_bytes = njobs * 8 * Bp * (Tinp + Tp)
+        part_extra = {"ms_per_step": pdt / a.steps * 1e3, "value": world * njobs * out_len * a.steps / pdt / 1e6, "unit": "Msamples/s",
+                      "partition": Bp, "blocks": Tp,
+                      "kernel_ms": {"k_fft_fwd": pk[0] / a.steps, "k_mac": pk[1] / a.steps, "k_fft_inv_mix_w": pk[2] / a.steps},
+                      "k_mac_GBs": mac_bytes / (pk[1] / a.steps * 1e-3) / 1e9 if pk[1] > 0 else None,
+                      "note": "wp_tune(WP_TUNE_CONV_FORM, 1): uniformly partitioned overlap-save, same entry point and results "
+                              "within 1e-5; reported beside the headline, which runs the form the library picks"}
+        convp.close()
+        irp.close()
+        del convp, irp
+        torch.cuda.empty_cache()
+
     verified = None
     if not a.no_verify and not fused:
         v = verify(w, rank, torch)
@@ -511,12 +553,15 @@ def main():
         dom = max(avg, key=avg.get)
         ach = alg[dom] / (avg[dom] * 1e-3) / 1e9
         traffic = None
+        config_form = ("long-frame: " + " + ".join("%dx%d" % (nf, n2) for n2, nf, hop, base in runs)) if lf else "partitioned: %d" % B
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC bytes per launch from the committed rocprofv3 passes
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                # counters are per launch of ONE workload: quote them only for that workload
+                tj = tj.get(a.config, tj)  # one entry per profiled configuration
+                # counters are per launch of ONE workload and one cover by frames: quote them only for those
                 same = tj.get("workload") == {"tracks_per_gpu": tracks, "frames": F, "ir_len": M, "path": a.path}
+                same = same and tj.get("form", config_form) == config_form
                 traffic = tj.get(dom) if same else None
             except Exception:
                 traffic = None
@@ -543,6 +588,8 @@ def main():
         }
         if fused_extra is not None:
             res["fused_path"] = fused_extra
+        if part_extra is not None:
+            res["partitioned_path"] = part_extra
         if c5_extra is not None:
             res["render_4s_ir"] = c5_extra
         if world == 1 and not a.no_cpu_baseline and a.cpu_tracks > 0:

@@ -32,19 +32,28 @@ const run = async device => {
   const store = new Map()
   const c0 = context(dry[0], 0, store)
   const reverb = await impulseReverbStereo(c0, { url: 'ir', id: 'bench' })
-  const bar = b => {
+  const parts = { reverb: 0, zero: 0, mix: 0 }  // host time spent inside each call (device work queued by a call may end later)
+  const bar = (b, timed) => {
     const c = context(dry[b & 3], b * L, store)
+    const t1 = timed ? now() : 0
     const wet = reverb(c)
+    const t2 = timed ? now() : 0
     bus.forEach(ch => ch.fill(0)) // Context.zero
+    const t3 = timed ? now() : 0
     mixBuffers(bus, [c.buffer, 1, 0.5, 0], [wet, 1, 0.5, 0])
+    if (timed) { const t4 = now(); parts.reverb += t2 - t1; parts.zero += t3 - t2; parts.mix += t4 - t3 }
   }
   const sync = () => device ? bus[0].subarray(0, 1).toFloat32Array() : bus[0]
-  for (let b = 0; b < 4; b++) bar(b)
+  for (let b = 0; b < 4; b++) bar(b, false)
   sync()
   const t0 = now()
-  for (let b = 0; b < bars; b++) bar(b)
+  for (let b = 0; b < bars; b++) bar(b, false)
   sync()
-  return (now() - t0) / bars
+  const per = (now() - t0) / bars
+  for (let b = 0; b < bars; b++) bar(b, true)
+  sync()
+  for (const k in parts) parts[k] = +(parts[k] / bars).toFixed(1)
+  return { per, parts }
 }
 
 const main = async () => {
@@ -61,9 +70,11 @@ const main = async () => {
   console.log(JSON.stringify({
     workload: 'stereo impulse-reverb + mix per bar, L=96000 @48 kHz, 2 s stereo IR, through the JS shims',
     bars,
-    us_per_bar_host_arrays: +host.toFixed(1),
-    us_per_bar_device_buffers: +device.toFixed(1),
-    realtime_factor_device: +((L / 48000) * 1e6 / device).toFixed(0),
+    us_per_bar_host_arrays: +host.per.toFixed(1),
+    us_per_bar_device_buffers: +device.per.toFixed(1),
+    host_us_inside_calls_host_arrays: host.parts,
+    host_us_inside_calls_device_buffers: device.parts,
+    realtime_factor_device: +((L / 48000) * 1e6 / device.per).toFixed(0),
     us_per_go_L44100_M22050_host_arrays: +c1.toFixed(1)
   }))
 }

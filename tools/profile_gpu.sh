@@ -8,8 +8,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 4 --warmup 2 --no-cpu-baseline --no-fused-extra --no-verify $*"
-PARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-fused-extra --no-verify $*"
+case "$*" in *"--config c5"*) export PROF_CONFIG=c5;; *) export PROF_CONFIG=c3;; esac
+ARGS="--steps 4 --warmup 2 --no-cpu-baseline --no-fused-extra --no-partitioned-extra --no-verify $*"
+PARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-fused-extra --no-partitioned-extra --no-verify $*"
 run() { name=$1; shift; echo "== $name"; timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" $BARGS > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }; }
 BARGS=$ARGS  run stats --kernel-trace --stats || exit 1
 if [ "${PROF_ONLY:-}" = "stats" ]; then python3 "$ROOT/tools/summarize_prof.py" "$OUT" | tee "$OUT/summary.txt"; exit 0; fi  # kernel trace only

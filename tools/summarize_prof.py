@@ -103,7 +103,8 @@ for k in acc:
 for base, (f, w) in tot.items():
     traffic[base] = int(2 * f * 1024 + w * 1024)
 print("# traffic bytes per step (2*FETCH_SIZE + WRITE_SIZE), all launches of a kernel family:", traffic)
-# the profiled command is the default bench workload (tools/profile_gpu.sh)
-traffic["workload"] = {"tracks_per_gpu": 256, "frames": 2880000, "ir_len": 96000, "path": "onepass"}
+# the profiled command is a bench workload (tools/profile_gpu.sh [--config c5]): PROF_CONFIG names it
+cfg = os.environ.get("PROF_CONFIG", "c3")
+traffic["workload"] = {"tracks_per_gpu": 256, "frames": 2880000, "ir_len": 192000 if cfg == "c5" else 96000, "path": "onepass"}
 with open(os.path.join(root, "traffic.json"), "w") as fh:
     json.dump(traffic, fh)
