@@ -80,6 +80,10 @@ PROTOTYPES = {
     "wp_comm_info": (C.c_int64, [C.c_void_p, C.c_int]),
     "wp_comm_library": (C.c_char_p, []),
     "wp_comm_available": (C.c_int, []),
+    "wp_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "wp_host_free": (None, [C.c_void_p]),
+    "wp_host_pin": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "wp_host_unpin": (C.c_int, [C.c_void_p]),
     "wp_lf_cover": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
     "wp_bus_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "wp_bus_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -332,6 +332,7 @@ static std::atomic<int> g_tune_lf_ab{0};    // WP_TUNE_LF_SPECTRA: 1 = plain ker
 static std::atomic<int> g_tune_lf_max{0};   // WP_TUNE_LF_MAX_FRAME: 0 = every frame size, n = frames of at most 2^n samples
 static std::atomic<int> g_tune_lf_min{0};   // WP_TUNE_LF_MIN_FRAME: 0 = every frame size, n = frames of at least 2^n samples
 static std::atomic<int> g_tune_lf_cost{0};  // WP_TUNE_LF_COST: 1 = covers priced by their bytes alone
+static std::atomic<int> g_tune_lf_split{0}; // WP_TUNE_LF_SPLIT: 1 = every run folds the bus inside its inverse pass, 2 = only the first run does
 static LfGeom choose_lf(int64_t L, int64_t M, int nch)
 {
     LfGeom best;
@@ -485,8 +486,14 @@ struct wp_conv {
     c32 *Z, *W;
     bool lf;            // long-frame form: A holds, run of frames after run, [njobs][nframes][R][C] instead of Z and W
     c32 *A;
-    hipStream_t side;   // plans with more than one run of frames: the shorter runs' inverse passes go here,
-    hipEvent_t fork, join;  // beside the first run's on the caller's stream
+    hipStream_t side[LF_MAX_SEG];   // plans with more than one run of frames: run i > 0's inverse pass goes to side[i],
+    hipEvent_t fork, join[LF_MAX_SEG];  // beside the first run's on the caller's stream
+    // a short run's bus fold as a pass of the mix kernel over its range of the bus (conv_back_lf): per run, the
+    // source table + the kernel's scratch on the device, a pinned mirror of the table and what it currently holds
+    void *mix_dev[LF_MAX_SEG];
+    wp_src *mix_pin[LF_MAX_SEG];
+    hipEvent_t mix_ev[LF_MAX_SEG];   // recorded behind the last upload from mix_pin[i]
+    std::vector<wp_src> mix_host[LF_MAX_SEG];
     // one stream at a time may use a plan (Z and W are shared by its calls): a call on a
     // different stream than the previous one first waits for that call's last kernel
     hipStream_t last_stream;
@@ -561,6 +568,10 @@ extern "C" int wp_tune(int what, int64_t value)
     case WP_TUNE_LF_COST:
         if (value < 0 || value > 1) break;
         g_tune_lf_cost = (int)value;
+        return WP_OK;
+    case WP_TUNE_LF_SPLIT:
+        if (value < 0 || value > 2) break;
+        g_tune_lf_split = (int)value;
         return WP_OK;
     case WP_TUNE_FWD_FORM:
         if (value < 0 || value > 2) break;
@@ -860,8 +871,14 @@ static void plan_geometry(wp_conv *c, wp_ir *ir, int njobs, int64_t out_len)
     c->Z = c->W = nullptr;
     c->lf = false;
     c->A = nullptr;
-    c->side = nullptr;
-    c->fork = c->join = nullptr;
+    c->fork = nullptr;
+    for (int i = 0; i < LF_MAX_SEG; i++) {
+        c->side[i] = nullptr;
+        c->join[i] = nullptr;
+        c->mix_dev[i] = nullptr;
+        c->mix_pin[i] = nullptr;
+        c->mix_ev[i] = nullptr;
+    }
     c->bytes = 0;
     c->prof = c->prof_valid = false;
     for (auto &e : c->ev) e = nullptr;
@@ -897,10 +914,10 @@ static wp_conv *conv_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t
     const size_t abytes = c->lf ? sizeof(c32) * (size_t)njobs * ir->lf.pts : 0;
     if (c->lf) {
         if (e == hipSuccess) e = hipMalloc((void **)&c->A, abytes);
-        if (ir->lf.nseg > 1) {
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join, hipEventDisableTiming);
+        if (ir->lf.nseg > 1 && e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+        for (int i = 1; i < ir->lf.nseg; i++) {
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
         }
     } else {
         if (e == hipSuccess) e = hipMalloc((void **)&c->Z, sbytes);
@@ -926,10 +943,15 @@ extern "C" void wp_conv_destroy(wp_conv *c)
     if (c->vol_dev) (void)hipFree(c->vol_dev);
     if (c->done) (void)hipEventDestroy(c->done);
     if (c->fork) (void)hipEventDestroy(c->fork);
-    if (c->join) (void)hipEventDestroy(c->join);
-    if (c->side) {
-        (void)hipStreamSynchronize(c->side);
-        (void)hipStreamDestroy(c->side);
+    for (int i = 0; i < LF_MAX_SEG; i++) {
+        if (c->side[i]) {
+            (void)hipStreamSynchronize(c->side[i]);
+            (void)hipStreamDestroy(c->side[i]);
+        }
+        if (c->join[i]) (void)hipEventDestroy(c->join[i]);
+        if (c->mix_ev[i]) (void)hipEventDestroy(c->mix_ev[i]);
+        if (c->mix_dev[i]) (void)hipFree(c->mix_dev[i]);
+        if (c->mix_pin[i]) (void)hipHostFree(c->mix_pin[i]);
     }
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -1057,38 +1079,122 @@ static int conv_front_lf(wp_conv *c, const float *in_dev, int64_t in_stride, int
     if (c->prof) HIPCHK(hipEventRecord(c->ev[2], s));
     return WP_OK;
 }
-// Inverse passes of every run of frames.  The runs write disjoint sample ranges; the shorter runs (few
-// workgroups, each a serial chain over the sources when the bus is folded) go to the plan's side
-// stream so that they overlap the first run's pass.
+// compute units of the current device (asked once per device)
+static int device_cus()
+{
+    static std::atomic<int> ncu[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = ncu[dev].load(std::memory_order_relaxed);
+    if (!n) {
+        hipDeviceProp_t prop;
+        n = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        ncu[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+// The bus fold of run i as a pass of the mix kernel over the run's range [lo, hi) of the bus, reading the results
+// the plain inverse pass has just written: sources s = rows (2s, 2s+1) of `out`, in order, the same arithmetic
+// as the fused fold (src/mix-buffers.js:49-52).
+static int lf_mix_range(wp_conv *c, int i, int64_t lo, int64_t hi, int nsrc, float *bus0, float *bus1, const float *out_dev,
+                        int64_t out_stride, hipStream_t q)
+{
+    const size_t tab_bytes = (sizeof(wp_src) * (size_t)nsrc + 255) & ~(size_t)255;
+    if (!c->mix_dev[i]) {
+        HIPCHK(hipMalloc(&c->mix_dev[i], tab_bytes + mix_scratch_bytes(nsrc)));
+        HIPCHK(hipHostMalloc((void **)&c->mix_pin[i], tab_bytes, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&c->mix_ev[i], hipEventDisableTiming));
+    }
+    std::vector<wp_src> tab((size_t)nsrc);
+    for (int s = 0; s < nsrc; s++) {
+        wp_src &S = tab[(size_t)s];
+        memset(&S, 0, sizeof(S));
+        S.ch[0] = out_dev + (int64_t)(2 * s) * out_stride + lo;
+        S.ch[1] = out_dev + (int64_t)(2 * s + 1) * out_stride + lo;
+        S.nch = 2;
+        S.rl = S.sl = hi - lo;
+        S.vol = c->vol_host[(size_t)s];
+        S.o = 0;
+    }
+    // an unchanged table (same result buffer and gains, bar after bar) is not uploaded again
+    if (c->mix_host[i].size() != tab.size() || memcmp(c->mix_host[i].data(), tab.data(), sizeof(wp_src) * tab.size()) != 0) {
+        if (!c->mix_host[i].empty()) HIPCHK(hipEventSynchronize(c->mix_ev[i]));  // the previous upload has left the mirror
+        c->mix_host[i].clear();
+        memcpy(c->mix_pin[i], tab.data(), sizeof(wp_src) * tab.size());
+        HIPCHK(hipMemcpyAsync(c->mix_dev[i], c->mix_pin[i], sizeof(wp_src) * tab.size(), hipMemcpyHostToDevice, q));
+        HIPCHK(hipEventRecord(c->mix_ev[i], q));
+        c->mix_host[i] = tab;
+    }
+    HIPCHK(launch_mix(bus0 + lo, bus1 + lo, 2, hi - lo, reinterpret_cast<const wp_src *>(c->mix_dev[i]), (char *)c->mix_dev[i] + tab_bytes,
+                      nsrc, q));
+    return WP_OK;
+}
+
+// Inverse passes of every run of frames.  The runs write disjoint sample ranges; every run after the first goes
+// to a side stream of its own, so that all of them overlap the first run's pass.  A bus-fold workgroup is a serial
+// chain over the sources; a run with too few tiles to give every CU one (the short runs at the end of a cover) would
+// spend the whole chain's latency on a fraction of the chip, so when the per-job results are written anyway such a
+// run takes the plain pass (one workgroup per job and tile) followed by the mix kernel over its range of the bus:
+// the same fold in the same order, at the price of reading that range's results back.
 static int conv_back_lf(wp_conv *c, int64_t limit, int nsrc, float *bus0, float *bus1, int64_t tl, const double *vol,
                         float *out_dev, int64_t out_stride, int64_t out_len, hipStream_t s)
 {
     const wp_ir *ir = c->ir;
-    bool forked = false;
+    bool forked = false, used[LF_MAX_SEG] = {false, false, false};
+    // Chains of the later runs only pay when they find room on the chip beside the first run's: a CU holds two
+    // bus-fold workgroups (registers), and the first run either fills both places of every CU for its whole
+    // duration or is launched one per CU (launch_lf_inv: when that needs fewer rounds), which leaves a place free.
+    const int ncu = device_cus();
+    int64_t room = 2 * (int64_t)ncu;
+    if (bus0 && out_dev && ir->lf.nseg > 0) {
+        const LfSeg &g0 = ir->lf.seg[0];
+        const int64_t units = (int64_t)(g0.C / (g0.R > 128 ? 16 : 32)) * lf_frames_run(g0, limit) * 2;
+        const int64_t one = (units + ncu - 1) / ncu, two = 2 * ((units + 2 * ncu - 1) / (2 * ncu));
+        room = (g0.R >= 128 && one < two) ? ncu : (units >= 2 * ncu ? 0 : 2 * ncu - units);
+    }
     for (int i = ir->lf.nseg - 1; i >= 0; i--) {
         const LfSeg &g = ir->lf.seg[i];
         const int fr = lf_frames_run(g, limit);
         if (fr <= 0) continue;
+        // a run that starts behind the end of the bus folds nothing: its results (if wanted) take the plain pass
+        bool fold = bus0 && g.base < tl;
+        if (!fold && !out_dev) continue;
         hipStream_t q = s;
-        if (i > 0 && c->side) {
+        if (i > 0 && c->side[i]) {
             if (!forked) {
                 HIPCHK(hipEventRecord(c->fork, s));
-                HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
                 forked = true;
             }
-            q = c->side;
+            HIPCHK(hipStreamWaitEvent(c->side[i], c->fork, 0));
+            q = c->side[i];
+            used[i] = true;
         }
-        // a run that starts behind the end of the bus folds nothing: its results (if wanted) take the plain pass, one
-        // workgroup per job and tile, instead of a serial walk over the sources
-        const bool fold = bus0 && g.base < tl;
-        if (!fold && !out_dev) continue;
+        const int cols = g.R > 128 ? 16 : 32;
+        const int64_t chains = (int64_t)(g.C / cols) * fr * 2;
+        bool split = false;
+        if (fold && out_dev && i > 0 && nsrc >= 8 && (int)c->vol_host.size() == nsrc && g_tune_lf_split != 1) {
+            if (chains <= room && g_tune_lf_split != 2)
+                room -= chains;
+            else
+                split = true;
+        }
+        if (split) fold = false;
         HIPCHK(launch_lf_inv(g.R, g.C, lf_seg_A(c, i), g.nframes, fr, c->njobs, g.base, g.hop, ir->lf.mpad, nsrc, fold ? bus0 : nullptr,
                              fold ? bus1 : nullptr, tl, vol, out_dev, out_stride, out_len, ir->lf_tab[i], q));
+        if (split) {
+            int64_t hi = g.base + (int64_t)fr * g.hop;
+            if (hi > tl) hi = tl;
+            if (hi > out_len) hi = out_len;
+            if (hi > g.base)
+                if (int rc = lf_mix_range(c, i, g.base, hi, nsrc, bus0, bus1, out_dev, out_stride, q)) return rc;
+        }
     }
-    if (forked) {
-        HIPCHK(hipEventRecord(c->join, c->side));
-        HIPCHK(hipStreamWaitEvent(s, c->join, 0));
-    }
+    for (int i = 1; i < LF_MAX_SEG; i++)
+        if (used[i]) {
+            HIPCHK(hipEventRecord(c->join[i], c->side[i]));
+            HIPCHK(hipStreamWaitEvent(s, c->join[i], 0));
+        }
     return WP_OK;
 }
 
@@ -1291,6 +1397,67 @@ extern "C" int wp_convolve_dev_noalloc(wp_ir *ir, int ch, const float *in_dev, i
     return WP_OK;
 }
 
+// The calling thread's stream for the host-pointer entry points (one per device): their transfers and
+// kernels are queued on it without a host round trip in between and awaited once, at the end of the call.
+// From page-locked host memory (wp_host_alloc, wp_host_pin) every transfer is a DMA straight from or to the
+// caller's array; pageable memory takes the runtime's staged path, as a blocking copy would.  The stream
+// is an ordinary (blocking) one, so the calls stay ordered with work a caller queued on the null stream.
+static int host_stream(hipStream_t *out)
+{
+    static thread_local std::map<int, hipStream_t> streams;  // released with the process
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    auto it = streams.find(dev);
+    if (it == streams.end()) {
+        hipStream_t s = nullptr;
+        HIPCHK(hipStreamCreate(&s));
+        it = streams.emplace(dev, s).first;
+    }
+    *out = it->second;
+    return WP_OK;
+}
+
+extern "C" void *wp_host_alloc(size_t bytes)
+{
+    if (need_device()) return nullptr;
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        fail(WP_ERR_HIP, "wp_host_alloc: %zu bytes of page-locked memory: %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void wp_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+extern "C" int wp_host_pin(void *p, size_t bytes)
+{
+    if (int rc = need_device()) return rc;
+    if (!p || !bytes) return fail(WP_ERR_INVALID, "wp_host_pin: null range");
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(WP_ERR_HIP, "wp_host_pin: %s", hipGetErrorString(e));
+    }
+    return WP_OK;
+}
+
+extern "C" int wp_host_unpin(void *p)
+{
+    if (!p) return WP_OK;
+    const hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(WP_ERR_HIP, "wp_host_unpin: %s", hipGetErrorString(e));
+    }
+    return WP_OK;
+}
+
 extern "C" int wp_convolve(wp_ir *ir, int ch, const float *in, int64_t in_len, float *out)
 {
     if (int rc = need_device()) return rc;
@@ -1302,9 +1469,12 @@ extern "C" int wp_convolve(wp_ir *ir, int ch, const float *in, int64_t in_len, f
         HIPCHK(hipMalloc((void **)&ir->stage_in, sizeof(float) * (size_t)(N + 2)));
         HIPCHK(hipMalloc((void **)&ir->stage_out, sizeof(float) * (size_t)(ir->L + ir->M + 2)));
     }
-    if (in_len > 0) HIPCHK(hipMemcpy(ir->stage_in, in, sizeof(float) * (size_t)in_len, hipMemcpyHostToDevice));
-    if (int rc = wp_convolve_dev(ir, ch, ir->stage_in, in_len, ir->stage_out, nullptr)) return rc;
-    HIPCHK(hipMemcpy(out, ir->stage_out, sizeof(float) * (size_t)(ir->L + ir->M), hipMemcpyDeviceToHost));
+    hipStream_t hs = nullptr;
+    if (int rc = host_stream(&hs)) return rc;
+    if (in_len > 0) HIPCHK(hipMemcpyAsync(ir->stage_in, in, sizeof(float) * (size_t)in_len, hipMemcpyHostToDevice, hs));
+    if (int rc = wp_convolve_dev(ir, ch, ir->stage_in, in_len, ir->stage_out, hs)) return rc;
+    HIPCHK(hipMemcpyAsync(out, ir->stage_out, sizeof(float) * (size_t)(ir->L + ir->M), hipMemcpyDeviceToHost, hs));
+    HIPCHK(hipStreamSynchronize(hs));
     return WP_OK;
 }
 
@@ -1469,14 +1639,17 @@ extern "C" int wp_reverb_block(wp_reverb *r, const float *const *in, int64_t in_
         HIPCHK(hipMalloc((void **)&r->stage_in, sizeof(float) * (size_t)r->njobs * (istride > 0 ? istride : 4)));
         r->stage_in_len = istride;
     }
+    hipStream_t hs = nullptr;
+    if (int rc = host_stream(&hs)) return rc;
     for (int j = 0; j < r->njobs; j++)
         if (in_len > 0)
-            HIPCHK(hipMemcpy(r->stage_in + (size_t)j * istride, in[j], sizeof(float) * (size_t)in_len, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpyAsync(r->stage_in + (size_t)j * istride, in[j], sizeof(float) * (size_t)in_len, hipMemcpyHostToDevice, hs));
     float *curr = nullptr;
     int64_t cs = 0;
-    if (int rc = wp_reverb_block_dev(r, r->stage_in, istride, in_len, &curr, &cs, v, nullptr)) return rc;
+    if (int rc = wp_reverb_block_dev(r, r->stage_in, istride, in_len, &curr, &cs, v, hs)) return rc;
     for (int j = 0; j < r->njobs; j++)
-        HIPCHK(hipMemcpy(out[j], curr + (size_t)j * cs, sizeof(float) * (size_t)(ir->L + ir->M), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(out[j], curr + (size_t)j * cs, sizeof(float) * (size_t)(ir->L + ir->M), hipMemcpyDeviceToHost, hs));
+    HIPCHK(hipStreamSynchronize(hs));
     return WP_OK;
 }
 
@@ -1716,13 +1889,15 @@ extern "C" int wp_mix(float *const *tgt, int tch, int64_t tl, const wp_src *srcs
         stage.cap = cap;
     }
     char *d = stage.p;
+    hipStream_t hs = nullptr;
+    if (int rc = host_stream(&hs)) return rc;
     for (const Arena &A : arenas) {
-        hipError_t e = hipMemcpy(d + A.off, A.lo, (size_t)(A.hi - A.lo), hipMemcpyHostToDevice);
+        hipError_t e = hipMemcpyAsync(d + A.off, A.lo, (size_t)(A.hi - A.lo), hipMemcpyHostToDevice, hs);
         if (e != hipSuccess) return fail(WP_ERR_HIP, "hipMemcpy(H2D) failed: %s", hipGetErrorString(e));
     }
     for (auto &kv : where) {
         if (kv.first.second == 0) continue;
-        hipError_t e = hipMemcpy(d + kv.second, kv.first.first, kv.first.second, hipMemcpyHostToDevice);
+        hipError_t e = hipMemcpyAsync(d + kv.second, kv.first.first, kv.first.second, hipMemcpyHostToDevice, hs);
         if (e != hipSuccess) return fail(WP_ERR_HIP, "hipMemcpy(H2D) failed: %s", hipGetErrorString(e));
     }
     auto dev_of = [&](const void *p, size_t bytes) -> char * {
@@ -1738,13 +1913,16 @@ extern "C" int wp_mix(float *const *tgt, int tch, int64_t tl, const wp_src *srcs
     }
     float *td[2] = {nullptr, nullptr};
     for (int c = 0; c < tch; c++) td[c] = reinterpret_cast<float *>(dev_of(tgt[c], sizeof(float) * (size_t)tl));
-    int rc = wp_mix_dev(td, tch, tl, ds.data(), nsrc, 0, nullptr);
+    int rc = wp_mix_dev(td, tch, tl, ds.data(), nsrc, 0, hs);
     if (rc == WP_OK) {
         for (int c = 0; c < tch && rc == WP_OK; c++) {
-            hipError_t e = hipMemcpy(tgt[c], td[c], sizeof(float) * (size_t)tl, hipMemcpyDeviceToHost);
+            hipError_t e = hipMemcpyAsync(tgt[c], td[c], sizeof(float) * (size_t)tl, hipMemcpyDeviceToHost, hs);
             if (e != hipSuccess) rc = fail(WP_ERR_HIP, "hipMemcpy(D2H) failed: %s", hipGetErrorString(e));
         }
     }
+    // awaited on every path: the staging area and the caller's arrays are free for reuse when the call returns
+    const hipError_t es = hipStreamSynchronize(hs);
+    if (rc == WP_OK && es != hipSuccess) rc = fail(WP_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(es));
     return rc;
 }
 

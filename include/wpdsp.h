@@ -283,6 +283,20 @@ int wp_bus_reduce(wp_comm *c, const float *send_dev, float *recv_dev, int64_t co
 /* The same with the sum delivered to every rank. */
 int wp_bus_allreduce(wp_comm *c, const float *send_dev, float *recv_dev, int64_t count, void *stream);
 
+/* ---- page-locked host memory -------------------------------------------------- */
+/* The reference's sample buffers are long-lived shared arrays handed round bar after bar
+ * (lib/shared-array-buffer.js:1-8, src/buffer-service.js:26-43, c.buffer of
+ * src/context.js).  A host array that the host-pointer entry points (wp_convolve,
+ * wp_reverb_block, wp_mix) see again and again is transferred by DMA straight from or to
+ * the array once it is page-locked; otherwise every transfer is staged through the
+ * runtime's bounce buffers.  wp_host_pin locks a range the caller owns (unlock before
+ * freeing it); wp_host_alloc returns page-locked memory (NULL on failure).  Results are
+ * the same either way. */
+void *wp_host_alloc(size_t bytes);
+void wp_host_free(void *p);
+int wp_host_pin(void *p, size_t bytes);
+int wp_host_unpin(void *p);
+
 /* ---- device-resident sample buffers ---------------------------------------- */
 /* The reference keeps samples in arrays of Float32Array channels over
  * SharedArrayBuffers that every worker sees (src/buffer-service.js:8-27,
@@ -341,6 +355,7 @@ double wp_bpm_from_beat_rate(double sample_rate, int64_t beat_rate);
 #define WP_TUNE_LF_MAX_FRAME 9  /* long-frame form: frames of at most 2^n samples (17..21; 0 = no limit) for IR handles created afterwards */
 #define WP_TUNE_LF_MIN_FRAME 10 /* long-frame form: frames of at least 2^n samples (17..21; 0 = no limit) */
 #define WP_TUNE_LF_COST 11 /* long-frame form: 1 = choose the cover by its bytes alone (0: measured per-shape kernel rates weigh in) */
+#define WP_TUNE_LF_SPLIT 12 /* long-frame form, one-pass results + bus: 1 = every run of frames folds the bus inside its inverse pass, 2 = every run after the first takes the plain pass + the mix kernel over its range, 0 = the later runs fold in their pass while the chip has room for their workgroups beside the first run's (takes effect at once) */
 #define WP_TUNE_FWD_FORM 4  /* forward transform: 1 one segment per workgroup, 2 two (the default; takes effect at once) */
 #define WP_TUNE_POOL_MB 3   /* cap of the wp_buf recycling pool in MiB (default 2048; 0 disables it) */
 int wp_tune(int what, int64_t value);

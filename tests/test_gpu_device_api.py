@@ -596,6 +596,19 @@ def test_long_frame_batch_row_pass_vs_oracle(torch, oracle, own_ir, L, M, frame0
     oracle.mix_buffers(want_bus, *[[[want[2 * s][:L], want[2 * s + 1][:L]], 1, vol[s], 0] for s in range(tracks)])
     for ch in range(2):
         assert float(np.abs(bus[ch].cpu().numpy().astype(np.float64) - want_bus[ch]).max()) <= TOL, ch
+    # the later runs of frames fold the bus inside their inverse pass or through the mix kernel over their range
+    # (WP_TUNE_LF_SPLIT 1 / 2; the library picks per run): the same fold in the same order, the same bits
+    for how in (1, 2):
+        capi.check(lib.wp_tune(12, how), "wp_tune")
+        try:
+            b2 = torch.zeros((2, L), dtype=torch.float32, device="cuda")
+            o2 = torch.empty((njobs, L + M), dtype=torch.float32, device="cuda")
+            conv.run_and_mix(xd, o2, [b2[0], b2[1]], vol)
+            torch.cuda.synchronize()
+        finally:
+            lib.wp_tune(12, 0)
+        assert torch.equal(b2.view(torch.int32), bus.view(torch.int32)), how
+        assert torch.equal(o2.view(torch.int32), out.view(torch.int32)), how
 
 
 def test_long_frame_edge_cases(torch, oracle):
