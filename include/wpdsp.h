@@ -286,12 +286,14 @@ int wp_bus_allreduce(wp_comm *c, const float *send_dev, float *recv_dev, int64_t
 /* ---- page-locked host memory -------------------------------------------------- */
 /* The reference's sample buffers are long-lived shared arrays handed round bar after bar
  * (lib/shared-array-buffer.js:1-8, src/buffer-service.js:26-43, c.buffer of
- * src/context.js).  A host array that the host-pointer entry points (wp_convolve,
- * wp_reverb_block, wp_mix) see again and again is transferred by DMA straight from or to
- * the array once it is page-locked; otherwise every transfer is staged through the
- * runtime's bounce buffers.  wp_host_pin locks a range the caller owns (unlock before
- * freeing it); wp_host_alloc returns page-locked memory (NULL on failure).  Results are
- * the same either way. */
+ * src/context.js).  When every host array of a call to the host-pointer entry points
+ * (wp_convolve, wp_reverb_block, wp_mix) is page-locked, the call's transfers are DMA
+ * straight from and to the arrays, queued with its kernels on a stream of the calling
+ * thread and awaited once; with a pageable array among them the call uses blocking
+ * copies through the runtime's bounce buffers.  wp_host_alloc returns page-locked
+ * memory (NULL on failure); wp_host_pin locks a range the caller owns (unlock it before
+ * freeing; a platform may refuse, e.g. inside some containers: WP_ERR_HIP, and the range
+ * simply stays pageable).  Results are the same either way. */
 void *wp_host_alloc(size_t bytes);
 void wp_host_free(void *p);
 int wp_host_pin(void *p, size_t bytes);

@@ -889,3 +889,58 @@ def test_two_host_threads_drive_two_plans_of_one_ir(torch, oracle):
     for t in threads:
         t.join(120)
     assert not errors, errors
+
+
+def test_host_pointer_calls_with_page_locked_arrays(torch, oracle):
+    """wp_reverb_block and wp_mix with every host array from wp_host_alloc (transfers queued on the calling
+    thread's stream, one wait) give the bits the same calls give with pageable arrays (blocking copies)."""
+    from dsp_amd import capi
+    lib = capi.lib()
+    L, M = 12000, 5000
+    f32p = C.POINTER(C.c_float)
+    irs = [oracle.synth_ir(M, 91), oracle.synth_ir(M, 92)]
+    h = capi.check_handle(lib.wp_ir_create((f32p * 2)(*[a.ctypes.data_as(f32p) for a in irs]), 2, M, L), "wp_ir_create")
+    job_ch = (C.c_int32 * 2)(0, 1)
+
+    def locked(n):
+        p = lib.wp_host_alloc(4 * n)
+        assert p, lib.wp_last_error()
+        return p, np.ctypeslib.as_array(C.cast(C.c_void_p(p), f32p), shape=(n,))
+
+    blocks = []
+    try:
+        results = {}
+        for kind in ("pageable", "locked"):
+            rv = capi.check_handle(lib.wp_reverb_create(h, 2, job_ch, 3), "wp_reverb_create")
+            if kind == "locked":
+                mem = [locked(L) for _ in range(2)] + [locked(L + M) for _ in range(2)] + [locked(L) for _ in range(2)]
+                blocks += [p for p, _ in mem]
+                xin, out, bus = [a for _, a in mem[:2]], [a for _, a in mem[2:4]], [a for _, a in mem[4:]]
+            else:
+                xin, out, bus = [np.empty(L, np.float32) for _ in range(2)], [np.empty(L + M, np.float32) for _ in range(2)], \
+                    [np.empty(L, np.float32) for _ in range(2)]
+            got = []
+            v = capi.WpReverbView()
+            for b in range(3):
+                for ch in range(2):
+                    xin[ch][:] = oracle.synth_noise(L, 95 + ch, b * L)
+                    bus[ch][:] = 0.125
+                capi.check(lib.wp_reverb_block(rv, (f32p * 2)(*[a.ctypes.data_as(f32p) for a in xin]), L,
+                                               (f32p * 2)(*[a.ctypes.data_as(f32p) for a in out]), C.byref(v)), "wp_reverb_block")
+                srcs = (capi.WpSrc * 2)()
+                for i, chans in enumerate((xin, [o[v.ret_off:v.ret_off + v.ret_len] for o in out])):
+                    srcs[i].nch = 2
+                    srcs[i].ch[0], srcs[i].ch[1] = chans[0].ctypes.data, chans[1].ctypes.data
+                    srcs[i].rl = srcs[i].sl = len(chans[0])
+                    srcs[i].vol, srcs[i].o = 0.5, 0
+                capi.check(lib.wp_mix((f32p * 2)(*[a.ctypes.data_as(f32p) for a in bus]), 2, L, srcs, 2), "wp_mix")
+                got.append([o.copy() for o in out] + [t.copy() for t in bus])
+            lib.wp_reverb_destroy(rv)
+            results[kind] = got
+        for a, b in zip(results["pageable"], results["locked"]):
+            for x, y in zip(a, b):
+                assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    finally:
+        for p in blocks:
+            lib.wp_host_free(C.c_void_p(p))
+        lib.wp_ir_destroy(h)
