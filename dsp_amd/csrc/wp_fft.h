@@ -204,10 +204,20 @@ constexpr int lds_points() { return B; }
 // compile-time constant for every access pattern of a plan whose stage-0 radix is 16 (checked for all
 // threads by tests/host_emu/fft_emu.cpp), so an exchange costs one address computation per butterfly and
 // immediate offsets, where the XOR layout costs two instructions per element.  Runs of 32 consecutive
-// elements stay conflict-free; the stage-0 stores (stride 16) become two-way conflicted.
+// elements stay conflict-free; the stage-0 stores (stride 16) would be two-way conflicted with lane = butterfly
+// (pad32_lane_butterfly below).
 WP_HD int lds_pad32(int i) { return i + (i >> 5); }
 template <int B>
 constexpr int lds_points32() { return B + B / 32; }
+// Which butterfly a lane takes on this layout.  ds_write_b64 is served in groups of 16 lanes over 16 eight-byte
+// slots, ds_read_b64 in groups of 32 lanes over 32 slots.  With butterfly = lane, the 16 lanes of a group store
+// their stage-0 outputs (16 consecutive points each) 16 points apart: slots (j >> 1) mod 16, every one taken
+// twice.  With bits 4..1 of the butterfly taken from the lane's low four bits and bit 0 = bit 4 ^ (lane bit 4),
+// a write group's stage-0 stores (slot = butterfly bits 4..1), its stride-16 stores (slot = low four bits + 8 *
+// bit 4) and its contiguous stores (slot = low four bits + const) each fall on 16 different slots, and a read
+// group still covers 32 consecutive points: every exchange of the plans with a stage-0 radix of 16 is free of
+// bank conflicts (tests/test_lds_layout.py).  A wave still covers 64 consecutive butterflies.
+WP_HD int pad32_lane_butterfly(int lane) { return (lane & ~31) | ((lane & 15) << 1) | (((lane >> 3) ^ (lane >> 4)) & 1); }
 // stage_store<B, S>: i = base + t*NS  ->  lds_pad32(i) = lds_pad32(base) + pad32_store_k<NS>(t)
 template <int NS>
 constexpr int pad32_store_k(int t)

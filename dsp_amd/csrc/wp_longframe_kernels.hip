@@ -244,7 +244,8 @@ __global__ __launch_bounds__(C / 8) void k_lf_mid_jobs(c32 *__restrict__ A, cons
     c32 *lds = reinterpret_cast<c32 *>(smem);
     constexpr int CP = lds_points32<C>();  // a row in LDS: one pad element per 32 (lds_pad32)
     c32 *tws = lds + 2 * CP;
-    const int tid = threadIdx.x, half = tid / NT, ft = tid & (NT - 1);
+    const int tid = threadIdx.x, half = tid / NT;
+    const int ft = pad32_lane_butterfly(tid & (NT - 1));  // the butterfly this lane takes: keeps every LDS exchange free of bank conflicts
     const int k1 = blockIdx.y, frame = blockIdx.z;
     const int job0 = blockIdx.x * JB, jend = job0 + JB < njobs ? job0 + JB : njobs;
     const int64_t Nc = (int64_t)R * C;
@@ -259,6 +260,21 @@ __global__ __launch_bounds__(C / 8) void k_lf_mid_jobs(c32 *__restrict__ A, cons
             int64_t at = ((int64_t)job * nframes + frame) * Nc + lf_col_off(int(t) * (C / 16));
             asm volatile("" : "+s"(at));
             v[t] = ld_nt(Arow + lf_col_off(ft) + at);
+        });
+    };
+    // The same rows through a buffer descriptor (the shared-spectra form): an unconditional load whose descriptor
+    // is empty behind the last job returns zeros without touching memory, so the registers of the rows in flight
+    // are defined anew in every pass and free between the top of a pass and the request.
+    const int row_u = __builtin_amdgcn_readfirstlane(row);  // the same in every lane of a wave (NT is a multiple of 64)
+    const c32 *__restrict__ Arow_u = A + lf_row_off(row_u, C);
+    constexpr uint32_t ROW_SPAN = (uint32_t)(lf_col_off(C - 1) + 1) * 8u;  // bytes from a row's first point to the end of its last
+    const int voff = lf_col_off(ft) * 8;
+    auto fetch_desc = [&](int job, bool live, c32 *v) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<c32 *>(Arow_u + ((int64_t)job * nframes + frame) * Nc), 0, live ? ROW_SPAN : 0u, 0x00020000);
+        static_for<0, 16>([&](auto t) {
+            const v2f p = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, lf_col_off(int(t) * (C / 16)) * 8, 2 /* non-temporal */));
+            v[t] = c32{p.x, p.y};
         });
     };
     const c32 wa = tab[LF_WA + k1];
@@ -276,7 +292,9 @@ __global__ __launch_bounds__(C / 8) void k_lf_mid_jobs(c32 *__restrict__ A, cons
     for (int job = job0; job < jend; job++) {
 #pragma unroll
         for (int i = 0; i < 16; i++) v[i] = vn[i];
-        if (job + 1 < jend) fetch(job + 1, vn);
+        if constexpr (!AB) {
+            if (job + 1 < jend) fetch(job + 1, vn);
+        }
         const int irch = job_irch ? job_irch[job] : irch_all;
         const c32 *ha = AB ? Hs + ((int64_t)irch * R + k1) * C * 2 : Hs + (int64_t)irch * R * C + lf_row_off(k1, C);
         const c32 *hb = AB ? Hs + ((int64_t)irch * R + (R - 1 - k1)) * C * 2 : Hs + (int64_t)irch * R * C + lf_row_off(R - 1 - k1, C);
@@ -300,34 +318,64 @@ __global__ __launch_bounds__(C / 8) void k_lf_mid_jobs(c32 *__restrict__ A, cons
         continue;
 #endif
         middle_stages32<C, false>(ff, v, ldsrow, tw);
-        __syncthreads();  // every lane has taken its last-stage inputs out of LDS
-        stage_store<C, LAST, false>(ff, v, [&](int i, c32 val, auto t, auto) {
-            ldsrow[lds_pad32(i - int(t) * NSL) + pad32_store_k<NSL>(int(t))] = val;
-        });
-        __syncthreads();
-        // bins k2 = tl + WGT*q of row k1 and their partners C-1-k2 of the other row: WGT + WGT/32 padded positions per q
-        c32 *za_p = lds + lds_pad32(tl), *zb_p = lds + CP + lds_pad32(C - 1 - tl);
-        static_for<0, C / WGT>([&](auto q) {
-            const int k2 = tl + WGT * int(q), p2 = C - 1 - k2;
-            c32 &za_s = za_p[(WGT + WGT / 32) * int(q)], &zb_s = zb_p[-(WGT + WGT / 32) * int(q)];
-            const c32 za = za_s, zb = zb_s;
-            if constexpr (AB) {
-                const c32x2 pa = reinterpret_cast<const c32x2 *>(ha)[k2], pb = reinterpret_cast<const c32x2 *>(hb)[p2];
-                za_s = lf_pair_product(pa, za, zb);
-                zb_s = lf_pair_product(pb, zb, za);
-            } else {
-                const c32 wp = c32{-wk[q].x, wk[q].y};  // the partner's factor: -conj(wk)
-                const c32 xa = bin_split(za, zb, wk[q]), xb = bin_split(zb, za, wp);
-                const c32 ya = cmul(xa, ha[lf_col_off(k2)]), yb = cmul(xb, hb[lf_col_off(p2)]);
-                za_s = bin_unsplit(ya, yb, wk[q]);
-                zb_s = bin_unsplit(yb, ya, wp);
-            }
-        });
-        __syncthreads();
-        int fi = ft;
+        int fi = ft;  // the inverse transform's copy of the index, hidden like ff
         asm volatile("" : "+v"(fi));
-        stage_load_t<C, 0>(fi, v, [&](int j, auto t, auto) { return ldsrow[lds_pad32(j) + pad32_load_k<C / 16>(int(t))]; });
-        __syncthreads();  // all stage-0 inputs are in registers before the first exchange overwrites the row
+        if constexpr (AB) {
+            // Own-bin form.  The forward transform leaves this thread with elements ff + NT*m of its row, m < 16:
+            // exactly the inputs of its inverse stage-0 butterfly.  Only their partners C-1-(ff + NT*m) of the
+            // other row have to come through LDS, and Y = alpha*z + beta*conj(z_partner) needs this bin's
+            // coefficients alone: 16 LDS stores and 16 loads per thread instead of 32 and 32, one barrier fewer.
+            // All sixteen coefficient loads are issued before the barriers (they are served by L2: their latency
+            // passes behind the exchange) and AHEAD of the next job's rows, so that waiting for them never waits
+            // for those rows; the rows are requested when half the coefficients have been used up.
+            const c32x2 *__restrict__ hrow = reinterpret_cast<const c32x2 *>(Hs + ((int64_t)irch * R + row) * C * 2) + ff;
+            c32x2 co[16];
+            static_for<0, 16>([&](auto m) { co[m] = hrow[NT * int(m)]; });
+            __syncthreads();  // every lane has taken its last-stage inputs out of LDS
+            stage_store<C, LAST, false>(ff, v, [&](int i, c32 val, auto t, auto) {
+                ldsrow[lds_pad32(i - int(t) * NSL) + pad32_store_k<NSL>(int(t))] = val;
+            });
+            __syncthreads();
+            constexpr int RL = FftPlan<C>::radix(LAST), NBL = 16 / RL;
+            c32 w[16];  // w[m] = element ff + NT*m (stage_store's output t of butterfly u is element ff + NT*(u + NBL*t))
+            static_for<0, NBL>([&](auto u) {
+                static_for<0, RL>([&](auto t) { w[int(u) + NBL * int(t)] = v[int(u) * RL + Dft<RL, false>::perm(int(t))]; });
+            });
+            const c32 *zb_p = lds + (half ? 0 : CP) + lds_pad32(C - 1 - ff);  // partner of element ff + NT*m: zb_p[-pad32_load_k<NT>(m)]
+            static_for<0, 8>([&](auto m) { v[m] = lf_pair_product(co[m], w[m], zb_p[-pad32_load_k<NT>(int(m))]); });
+            asm volatile("" ::: "memory");
+            fetch_desc(job + 1, job + 1 < jend, vn);
+            asm volatile("" ::: "memory");
+            static_for<8, 16>([&](auto m) { v[m] = lf_pair_product(co[m], w[m], zb_p[-pad32_load_k<NT>(int(m))]); });
+            __syncthreads();  // every partner has been read before the inverse transform's first exchange overwrites the rows
+        } else {
+            __syncthreads();  // every lane has taken its last-stage inputs out of LDS
+            stage_store<C, LAST, false>(ff, v, [&](int i, c32 val, auto t, auto) {
+                ldsrow[lds_pad32(i - int(t) * NSL) + pad32_store_k<NSL>(int(t))] = val;
+            });
+            __syncthreads();
+            // bins k2 = tl + WGT*q of row k1 and their partners C-1-k2 of the other row: WGT + WGT/32 padded positions per q
+            c32 *za_p = lds + lds_pad32(tl), *zb_p = lds + CP + lds_pad32(C - 1 - tl);
+            static_for<0, C / WGT>([&](auto q) {
+                const int k2 = tl + WGT * int(q), p2 = C - 1 - k2;
+                c32 &za_s = za_p[(WGT + WGT / 32) * int(q)], &zb_s = zb_p[-(WGT + WGT / 32) * int(q)];
+                const c32 za = za_s, zb = zb_s;
+                if constexpr (AB) {
+                    const c32x2 pa = reinterpret_cast<const c32x2 *>(ha)[k2], pb = reinterpret_cast<const c32x2 *>(hb)[p2];
+                    za_s = lf_pair_product(pa, za, zb);
+                    zb_s = lf_pair_product(pb, zb, za);
+                } else {
+                    const c32 wp = c32{-wk[q].x, wk[q].y};  // the partner's factor: -conj(wk)
+                    const c32 xa = bin_split(za, zb, wk[q]), xb = bin_split(zb, za, wp);
+                    const c32 ya = cmul(xa, ha[lf_col_off(k2)]), yb = cmul(xb, hb[lf_col_off(p2)]);
+                    za_s = bin_unsplit(ya, yb, wk[q]);
+                    zb_s = bin_unsplit(yb, ya, wp);
+                }
+            });
+            __syncthreads();
+            stage_load_t<C, 0>(fi, v, [&](int j, auto t, auto) { return ldsrow[lds_pad32(j) + pad32_load_k<C / 16>(int(t))]; });
+            __syncthreads();  // all stage-0 inputs are in registers before the first exchange overwrites the row
+        }
         middle_stages32<C, true>(fi, v, ldsrow, tw);
         stage_store<C, LAST, true>(fi, v, [&](int i, c32 val, auto t, auto) {
             int64_t at = ((int64_t)job * nframes + frame) * Nc + lf_col_off(int(t) * NSL);
