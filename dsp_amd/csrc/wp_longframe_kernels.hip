@@ -292,17 +292,23 @@ __global__ __launch_bounds__(C / 8) void k_lf_mid_jobs(c32 *__restrict__ A, cons
     for (int job = job0; job < jend; job++) {
 #pragma unroll
         for (int i = 0; i < 16; i++) v[i] = vn[i];
-        if constexpr (!AB) {
-            if (job + 1 < jend) fetch(job + 1, vn);
-        }
         const int irch = job_irch ? job_irch[job] : irch_all;
-        const c32 *ha = AB ? Hs + ((int64_t)irch * R + k1) * C * 2 : Hs + (int64_t)irch * R * C + lf_row_off(k1, C);
-        const c32 *hb = AB ? Hs + ((int64_t)irch * R + (R - 1 - k1)) * C * 2 : Hs + (int64_t)irch * R * C + lf_row_off(R - 1 - k1, C);
         // the thread indices are hidden from the optimiser once per job (and once more between the two
         // transforms): every LDS address and twiddle power derived from them would otherwise be computed
         // once, ahead of the loop, and held in some 150 registers across it
         int ff = ft, tl = tid;
         asm volatile("" : "+v"(ff), "+v"(tl));
+        // A kernel spectrum of the job's own comes from HBM: its bins k2 = tl + WGT*q of row k1 and C-1-k2 of the
+        // other row are requested here, a whole forward transform ahead of their use (they lie like a frame of A).
+        c32 hA[AB ? 1 : C / WGT], hB[AB ? 1 : C / WGT];
+        if constexpr (!AB) {
+            const c32 *__restrict__ ha = Hs + (int64_t)irch * R * C + lf_row_off(k1, C) + lf_col_off(tl);
+            const c32 *__restrict__ hb = Hs + (int64_t)irch * R * C + lf_row_off(R - 1 - k1, C) + lf_col_off(C - 1 - tl);
+            static_for<0, C / WGT>([&](auto q) {
+                hA[q] = ha[lf_col_off(WGT * int(q))];
+                hB[q] = hb[-lf_col_off(WGT * int(q))];
+            });
+        }
 #if defined(WP_MID_ABLATE)  // measurement builds only: 1 = rows copied through registers, 2 = forward transform only
         if (WP_MID_ABLATE == 2) middle_stages32<C, false>(ff, v, ldsrow, tw);
         stage_store<C, LAST, false>(ff, v, [&](int i, c32 val, auto t, auto) {
@@ -356,22 +362,20 @@ __global__ __launch_bounds__(C / 8) void k_lf_mid_jobs(c32 *__restrict__ A, cons
             __syncthreads();
             // bins k2 = tl + WGT*q of row k1 and their partners C-1-k2 of the other row: WGT + WGT/32 padded positions per q
             c32 *za_p = lds + lds_pad32(tl), *zb_p = lds + CP + lds_pad32(C - 1 - tl);
-            static_for<0, C / WGT>([&](auto q) {
-                const int k2 = tl + WGT * int(q), p2 = C - 1 - k2;
+            auto pairs = [&](auto q) {
                 c32 &za_s = za_p[(WGT + WGT / 32) * int(q)], &zb_s = zb_p[-(WGT + WGT / 32) * int(q)];
                 const c32 za = za_s, zb = zb_s;
-                if constexpr (AB) {
-                    const c32x2 pa = reinterpret_cast<const c32x2 *>(ha)[k2], pb = reinterpret_cast<const c32x2 *>(hb)[p2];
-                    za_s = lf_pair_product(pa, za, zb);
-                    zb_s = lf_pair_product(pb, zb, za);
-                } else {
-                    const c32 wp = c32{-wk[q].x, wk[q].y};  // the partner's factor: -conj(wk)
-                    const c32 xa = bin_split(za, zb, wk[q]), xb = bin_split(zb, za, wp);
-                    const c32 ya = cmul(xa, ha[lf_col_off(k2)]), yb = cmul(xb, hb[lf_col_off(p2)]);
-                    za_s = bin_unsplit(ya, yb, wk[q]);
-                    zb_s = bin_unsplit(yb, ya, wp);
-                }
-            });
+                const c32 wp = c32{-wk[q].x, wk[q].y};  // the partner's factor: -conj(wk)
+                const c32 xa = bin_split(za, zb, wk[q]), xb = bin_split(zb, za, wp);
+                const c32 ya = cmul(xa, hA[q]), yb = cmul(xb, hB[q]);
+                za_s = bin_unsplit(ya, yb, wk[q]);
+                zb_s = bin_unsplit(yb, ya, wp);
+            };
+            static_for<0, C / WGT / 2>(pairs);
+            asm volatile("" ::: "memory");
+            fetch_desc(job + 1, job + 1 < jend, vn);  // behind this job's kernel-spectrum loads: waiting for those never waits for these
+            asm volatile("" ::: "memory");
+            static_for<C / WGT / 2, C / WGT>(pairs);
             __syncthreads();
             stage_load_t<C, 0>(fi, v, [&](int j, auto t, auto) { return ldsrow[lds_pad32(j) + pad32_load_k<C / 16>(int(t))]; });
             __syncthreads();  // all stage-0 inputs are in registers before the first exchange overwrites the row
