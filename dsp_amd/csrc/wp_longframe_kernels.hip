@@ -305,8 +305,8 @@ __global__ __launch_bounds__(C / 8) void k_lf_mid_jobs(c32 *__restrict__ A, cons
             const c32 *__restrict__ ha = Hs + (int64_t)irch * R * C + lf_row_off(k1, C) + lf_col_off(tl);
             const c32 *__restrict__ hb = Hs + (int64_t)irch * R * C + lf_row_off(R - 1 - k1, C) + lf_col_off(C - 1 - tl);
             static_for<0, C / WGT>([&](auto q) {
-                hA[q] = ha[lf_col_off(WGT * int(q))];
-                hB[q] = hb[-lf_col_off(WGT * int(q))];
+                hA[q] = ld_nt(ha + lf_col_off(WGT * int(q)));
+                hB[q] = ld_nt(hb - lf_col_off(WGT * int(q)));
             });
         }
 #if defined(WP_MID_ABLATE)  // measurement builds only: 1 = rows copied through registers, 2 = forward transform only
