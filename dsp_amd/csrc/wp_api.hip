@@ -333,6 +333,7 @@ static std::atomic<int> g_tune_lf_ab{0};    // WP_TUNE_LF_SPECTRA: 1 = plain ker
 static std::atomic<int> g_tune_lf_max{0};   // WP_TUNE_LF_MAX_FRAME: 0 = every frame size, n = frames of at most 2^n samples
 static std::atomic<int> g_tune_lf_min{0};   // WP_TUNE_LF_MIN_FRAME: 0 = every frame size, n = frames of at least 2^n samples
 static std::atomic<int> g_tune_lf_cost{0};  // WP_TUNE_LF_COST: 1 = covers priced by their bytes alone
+static std::atomic<int> g_tune_lf_wide{0};  // WP_TUNE_LF_WIDE: 1 = bus-fold chains over tiles of 16 columns only (frames of 256 rows), 2 = of 32 only
 static std::atomic<int> g_tune_lf_split{0}; // WP_TUNE_LF_SPLIT: 1 = every run folds the bus inside its inverse pass, 2 = only the first run does
 static LfGeom choose_lf(int64_t L, int64_t M, int nch)
 {
@@ -489,6 +490,7 @@ struct wp_conv {
     c32 *A;
     hipStream_t side[LF_MAX_SEG];   // plans with more than one run of frames: run i > 0's inverse pass goes to side[i],
     hipEvent_t fork, join[LF_MAX_SEG];  // beside the first run's on the caller's stream
+    int wide_frames = 0, wide_for = -1;  // run 0's frames whose bus-fold chains take the wide tiles, chosen for wide_for frames run
     // a short run's bus fold as a pass of the mix kernel over its range of the bus (conv_back_lf): per run, the
     // source table + the kernel's scratch on the device, a pinned mirror of the table and what it currently holds
     void *mix_dev[LF_MAX_SEG];
@@ -573,6 +575,10 @@ extern "C" int wp_tune(int what, int64_t value)
     case WP_TUNE_LF_SPLIT:
         if (value < 0 || value > 2) break;
         g_tune_lf_split = (int)value;
+        return WP_OK;
+    case WP_TUNE_LF_WIDE:
+        if (value < 0 || value > 2) break;
+        g_tune_lf_wide = (int)value;
         return WP_OK;
     case WP_TUNE_FWD_FORM:
         if (value < 0 || value > 2) break;
@@ -915,8 +921,10 @@ static wp_conv *conv_create(wp_ir *ir, int njobs, const int32_t *job_ch, int64_t
     const size_t abytes = c->lf ? sizeof(c32) * (size_t)njobs * ir->lf.pts : 0;
     if (c->lf) {
         if (e == hipSuccess) e = hipMalloc((void **)&c->A, abytes);
-        if (ir->lf.nseg > 1 && e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
-        for (int i = 1; i < ir->lf.nseg; i++) {
+        // (run 0 has a side stream too when its frames have 256 rows: its bus-fold pass may be split in two launches)
+        const int first_side = ir->lf.seg[0].R == 256 ? 0 : 1;
+        if ((ir->lf.nseg > 1 || first_side == 0) && e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+        for (int i = first_side; i < ir->lf.nseg; i++) {
             if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
         }
@@ -1132,6 +1140,43 @@ static int lf_mix_range(wp_conv *c, int i, int64_t lo, int64_t hi, int nsrc, flo
     return WP_OK;
 }
 
+// Bus-fold chains of a run whose frames have 256 rows, results written as well: how many of its first frames take
+// tiles of 32 columns (256-byte runs; a chain of 512 threads that has a CU to itself and takes 1.5 times as long as
+// a chain over a tile of 16 columns does, for twice the samples), the rest 16.  Chosen for the shortest schedule of
+// the chains on the CUs, one chain per CU at a time, the long ones first; ties go to the wider tiles.
+static int lf_wide_frames(int C, int fr, int ncu)
+{
+    if (g_tune_lf_wide == 1) return 0;
+    if (g_tune_lf_wide == 2) return fr;
+    int best = 0;
+    int64_t best_t = -1;
+    const int lo = fr > 8 ? fr - 8 : 0;  // with many frames the few last ones decide how the schedule ends
+    for (int wide = fr; wide >= lo; wide--) {
+        // loads in half units: a wide chain 3, a narrow one 2
+        const int64_t nw = (int64_t)(C / 32) * wide * 2, nn = (int64_t)(C / 16) * (fr - wide) * 2;
+        std::map<int64_t, int64_t> level;  // load -> CUs at that load
+        const int64_t a = nw / ncu, r = nw % ncu;
+        if (r) level[3 * (a + 1)] += r;
+        level[3 * a] += ncu - r;
+        for (int64_t left = nn; left > 0;) {
+            auto it = level.begin();
+            const int64_t k = it->second < left ? it->second : left, at = it->first;
+            if (k == it->second)
+                level.erase(it);
+            else
+                it->second -= k;
+            level[at + 2] += k;
+            left -= k;
+        }
+        const int64_t t = level.rbegin()->first;
+        if (best_t < 0 || t < best_t) {
+            best_t = t;
+            best = wide;
+        }
+    }
+    return best;
+}
+
 // Inverse passes of every run of frames.  The runs write disjoint sample ranges; every run after the first goes
 // to a side stream of its own, so that all of them overlap the first run's pass.  A bus-fold workgroup is a serial
 // chain over the sources; a run with too few tiles to give every CU one (the short runs at the end of a cover) would
@@ -1148,11 +1193,21 @@ static int conv_back_lf(wp_conv *c, int64_t limit, int nsrc, float *bus0, float 
     // duration or is launched one per CU (launch_lf_inv: when that needs fewer rounds), which leaves a place free.
     const int ncu = device_cus();
     int64_t room = 2 * (int64_t)ncu;
+    int wide0 = 0;  // frames of run 0 whose chains take the wide tiles
     if (bus0 && out_dev && ir->lf.nseg > 0) {
         const LfSeg &g0 = ir->lf.seg[0];
-        const int64_t units = (int64_t)(g0.C / (g0.R > 128 ? 16 : 32)) * lf_frames_run(g0, limit) * 2;
+        const int fr0 = lf_frames_run(g0, limit);
+        if (g0.R == 256 && c->side[0] && g0.base < tl && fr0 > 0) {
+            if (c->wide_for != fr0) {
+                c->wide_frames = lf_wide_frames(g0.C, fr0, ncu);
+                c->wide_for = fr0;
+            }
+            wide0 = c->wide_frames;
+        }
+        const int64_t units = (int64_t)(g0.C / (g0.R > 128 ? 16 : 32)) * fr0 * 2;
         const int64_t one = (units + ncu - 1) / ncu, two = 2 * ((units + 2 * ncu - 1) / (2 * ncu));
         room = (g0.R >= 128 && one < two) ? ncu : (units >= 2 * ncu ? 0 : 2 * ncu - units);
+        if (wide0 > 0) room = 0;  // a wide chain leaves no registers for another beside it
     }
     for (int i = ir->lf.nseg - 1; i >= 0; i--) {
         const LfSeg &g = ir->lf.seg[i];
@@ -1181,8 +1236,24 @@ static int conv_back_lf(wp_conv *c, int64_t limit, int nsrc, float *bus0, float 
                 split = true;
         }
         if (split) fold = false;
-        HIPCHK(launch_lf_inv(g.R, g.C, lf_seg_A(c, i), g.nframes, fr, c->njobs, g.base, g.hop, ir->lf.mpad, nsrc, fold ? bus0 : nullptr,
-                             fold ? bus1 : nullptr, tl, vol, out_dev, out_stride, out_len, ir->lf_tab[i], q));
+        if (i == 0 && fold && wide0 > 0) {
+            // the wide chains first, on the caller's stream; the narrow ones of the remaining frames beside them
+            HIPCHK(launch_lf_inv(g.R, g.C, lf_seg_A(c, i), g.nframes, 0, wide0, c->njobs, g.base, g.hop, ir->lf.mpad, nsrc, bus0, bus1, tl, vol,
+                                 out_dev, out_stride, out_len, ir->lf_tab[i], true, s));
+            if (wide0 < fr) {
+                if (!forked) {
+                    HIPCHK(hipEventRecord(c->fork, s));
+                    forked = true;
+                }
+                HIPCHK(hipStreamWaitEvent(c->side[0], c->fork, 0));
+                used[0] = true;
+                HIPCHK(launch_lf_inv(g.R, g.C, lf_seg_A(c, i), g.nframes, wide0, fr - wide0, c->njobs, g.base, g.hop, ir->lf.mpad, nsrc, bus0, bus1,
+                                     tl, vol, out_dev, out_stride, out_len, ir->lf_tab[i], false, c->side[0]));
+            }
+            continue;
+        }
+        HIPCHK(launch_lf_inv(g.R, g.C, lf_seg_A(c, i), g.nframes, 0, fr, c->njobs, g.base, g.hop, ir->lf.mpad, nsrc, fold ? bus0 : nullptr,
+                             fold ? bus1 : nullptr, tl, vol, out_dev, out_stride, out_len, ir->lf_tab[i], false, q));
         if (split) {
             int64_t hi = g.base + (int64_t)fr * g.hop;
             if (hi > tl) hi = tl;
@@ -1191,7 +1262,7 @@ static int conv_back_lf(wp_conv *c, int64_t limit, int nsrc, float *bus0, float 
                 if (int rc = lf_mix_range(c, i, g.base, hi, nsrc, bus0, bus1, out_dev, out_stride, q)) return rc;
         }
     }
-    for (int i = 1; i < LF_MAX_SEG; i++)
+    for (int i = 0; i < LF_MAX_SEG; i++)
         if (used[i]) {
             HIPCHK(hipEventRecord(c->join[i], c->side[i]));
             HIPCHK(hipStreamWaitEvent(s, c->join[i], 0));

@@ -71,9 +71,9 @@ hipError_t launch_lf_mid(bool hprep, bool ab, int R, int C, c32 *A, c32 *Hs, con
                          int frames_run, int njobs, const c32 *tab, const c32 *tab_row, hipStream_t s);
 // bus0 == nullptr: plain results for every job; otherwise the bus fold over nsrc stereo sources (jobs 2s, 2s+1),
 // with the per-job results too when out != nullptr
-hipError_t launch_lf_inv(int R, int C, const c32 *A, int nframes, int frames_run, int njobs, int64_t base, int64_t hop, int64_t mpad, int nsrc,
-                         float *bus0, float *bus1, int64_t tl, const double *vol, float *out, int64_t out_stride,
-                         int64_t out_len, const c32 *tab, hipStream_t s);
+hipError_t launch_lf_inv(int R, int C, const c32 *A, int nframes, int frame0, int frames_run, int njobs, int64_t base, int64_t hop, int64_t mpad,
+                         int nsrc, float *bus0, float *bus1, int64_t tl, const double *vol, float *out, int64_t out_stride,
+                         int64_t out_len, const c32 *tab, bool wide, hipStream_t s);
 // out[job][i] += prev[job][i], i < prev_len (the carried reverb tail, lib/impulse-reverb.js:14-16)
 hipError_t launch_add_prev(float *out, int64_t out_stride, const float *prev, int64_t prev_stride, int64_t prev_len, int njobs,
                            hipStream_t s);

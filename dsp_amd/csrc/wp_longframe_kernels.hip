@@ -36,7 +36,7 @@
 
 namespace wp {
 
-constexpr int LF_COLS = 32;  // columns per tile: 32 complex points = one 256-byte run per row
+// (tiles of the column passes are COLS columns wide: 32 complex points = one 256-byte run per row)
 
 // exp(-2*pi*i*idx/Nc), idx < Nc, from the two-level table (both factors correctly rounded)
 __device__ __forceinline__ c32 lf_w(const c32 *__restrict__ tab, int idx)
@@ -67,8 +67,8 @@ __device__ __forceinline__ TwTables<R> lf_col_tables(const c32 *__restrict__ tab
 // Forward column pass.  Workgroup = tile of 32 columns of one frame of one job; thread = (column,
 // j) with R/16 threads per column transform.  IRMODE: the "frame" is the impulse response itself,
 // starting at sample 0.
-template <int R, int C>
-__global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_fwd(const float *__restrict__ in, int64_t in_stride, int64_t in_len,
+template <int R, int C, int COLS>
+__global__ __launch_bounds__(COLS *R / 16) void k_lf_fwd(const float *__restrict__ in, int64_t in_stride, int64_t in_len,
                                                             c32 *__restrict__ A, int nframes, int64_t base, int64_t hop,
                                                             int64_t mpad, const c32 *__restrict__ tab)
 {
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_fwd(const float *__restr
     constexpr int64_t Nc = (int64_t)R * C;
     extern __shared__ __align__(16) unsigned char smem[];
     c32 *lds = reinterpret_cast<c32 *>(smem);
-    const int col = threadIdx.x & (LF_COLS - 1), j = threadIdx.x >> 5;
-    const int c = blockIdx.x * LF_COLS + col;
+    const int col = threadIdx.x & (COLS - 1), j = threadIdx.x / COLS;
+    const int c = blockIdx.x * COLS + col;
     const int frame = blockIdx.y, job = blockIdx.z;
     const TwTables<R> tw = lf_col_tables<R>(tab);
     const float *x = in + (int64_t)job * in_stride;
@@ -112,9 +112,9 @@ __global__ __launch_bounds__(LF_COLS *R / 16) void k_lf_fwd(const float *__restr
         static_for<0, PT>([&](auto t) { v[t] = cmul(v[t], mul_w32<int(t), false>(f)); });
     }
     stage_compute<R, 0, false>(j, v, tw);
-    stage_store<R, 0, false>(j, v, [&](int i, c32 val, int, int) { lds[i * LF_COLS + col] = val; });
+    stage_store<R, 0, false>(j, v, [&](int i, c32 val, int, int) { lds[i * COLS + col] = val; });
     __syncthreads();
-    stage_load<R, 1>(j, v, [&](int i) { return lds[i * LF_COLS + col]; });
+    stage_load<R, 1>(j, v, [&](int i) { return lds[i * COLS + col]; });
     stage_compute<R, 1, false>(j, v, tw);
     // outputs k1 = j' + 16*t (j' = j + u*NTF), times exp(-2*pi*i*c*k1/Nc) = W^(c*j') * (W^(16c))^t
     constexpr int R1 = FftPlan<R>::radix(1), NB = PT / R1;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(C / 8) void k_lf_mid_jobs(c32 *__restrict__ A, cons
 // COLS: columns per tile (32, or 16 for R = 256 so that the workgroup stays at 256 threads: with 512 the
 // bus-fold variants need more registers than two waves per SIMD leave and spill).
 template <int R, int C, int COLS, bool MIX, bool WRITE>
-__global__ __launch_bounds__(COLS *R / 16) void k_lf_inv(const c32 *__restrict__ A, int nframes, int64_t base, int64_t hop,
+__global__ __launch_bounds__(COLS *R / 16) void k_lf_inv(const c32 *__restrict__ A, int nframes, int frame0, int64_t base, int64_t hop,
                                                             int64_t mpad, int nsrc, float *__restrict__ bus0, float *__restrict__ bus1,
                                                             int64_t tl, const double *__restrict__ vol, float *__restrict__ out,
                                                             int64_t out_stride, int64_t out_len, const c32 *__restrict__ tab)
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(COLS *R / 16) void k_lf_inv(const c32 *__restrict__
     c32 *lds = reinterpret_cast<c32 *>(smem);
     const int col = threadIdx.x & (COLS - 1), j = threadIdx.x / COLS;
     const int c = blockIdx.x * COLS + col;
-    const int frame = blockIdx.y;
+    const int frame = frame0 + blockIdx.y;
     const TwTables<R> tw = lf_col_tables<R>(tab);
     // inputs k1 = j + t*NTF: conj of exp(-2*pi*i*c*k1/Nc) = conj(W^(c*j)) * conj(W^(c*NTF))^t
     c32 tin[PT];
@@ -627,9 +627,13 @@ template <int R, int C>
 static hipError_t lf_fwd_t(const float *in, int64_t in_stride, int64_t in_len, c32 *A, int nframes, int frames_run, int njobs,
                            int64_t base, int64_t hop, int64_t mpad, const c32 *tab, hipStream_t s)
 {
-    const size_t lds = sizeof(c32) * R * LF_COLS;
-    if (hipError_t e = lf_lds(k_lf_fwd<R, C>, lds)) return e;
-    hipLaunchKernelGGL((k_lf_fwd<R, C>), dim3(C / LF_COLS, frames_run, njobs), dim3(LF_COLS * R / 16), lds, s, in, in_stride, in_len,
+#ifndef WP_FWD_COLS
+#define WP_FWD_COLS 32
+#endif
+    constexpr int FC = WP_FWD_COLS * R / 16 > 1024 ? 1024 * 16 / R : WP_FWD_COLS;  // columns per tile
+    const size_t lds = sizeof(c32) * R * FC;
+    if (hipError_t e = lf_lds(k_lf_fwd<R, C, FC>, lds)) return e;
+    hipLaunchKernelGGL((k_lf_fwd<R, C, FC>), dim3(C / FC, frames_run, njobs), dim3(FC * R / 16), lds, s, in, in_stride, in_len,
                        A, nframes, base, hop, mpad, tab);
     return hipGetLastError();
 }
@@ -705,15 +709,17 @@ static int lf_cu_count()
     return n;
 }
 
-template <int R, int C>
-static hipError_t lf_inv_t(const c32 *A, int nframes, int frames_run, int njobs, int64_t base, int64_t hop, int64_t mpad, int nsrc, float *bus0, float *bus1,
-                           int64_t tl, const double *vol, float *out, int64_t out_stride, int64_t out_len, const c32 *tab,
-                           hipStream_t s)
+// Columns per tile of the bus-fold variants.  Frames of 256 rows: 16 (workgroups of 256 threads, 128-byte runs)
+// or, `wide`, 32 (512 threads, 256-byte runs: a chain then takes 1.5 times as long for twice the samples, but only
+// one workgroup fits a CU).  Smaller frames: 32.
+template <int R, int C, int COLS>
+static hipError_t lf_inv_fold_t(const c32 *A, int nframes, int frame0, int frames_run, int64_t base, int64_t hop, int64_t mpad, int nsrc,
+                                float *bus0, float *bus1, int64_t tl, const double *vol, float *out, int64_t out_stride, int64_t out_len,
+                                const c32 *tab, hipStream_t s)
 {
-    constexpr int COLS = R > 128 ? 16 : 32;
-    size_t lds = sizeof(c32) * R * COLS * (bus0 ? 2 : 1);  // the bus-fold variants keep their input twiddles behind the tile
+    size_t lds = sizeof(c32) * R * COLS * 2;  // the bus-fold variants keep their input twiddles behind the tile
     const dim3 block(COLS * R / 16);
-    if (bus0 && out && block.x == 256) {
+    if (out && block.x == 256) {
         // (measured for the variant that also writes the sources' samples; the bus-only one gains from two per CU)
         // A bus-fold workgroup is one long serial chain over the sources, and two of them on a CU run at half
         // speed each: the pass takes (rounds of workgroups) x (workgroups per CU).  Two per CU fit; when one per
@@ -724,32 +730,54 @@ static hipError_t lf_inv_t(const c32 *A, int nframes, int frames_run, int njobs,
         const int64_t one = (units + ncu - 1) / ncu, two = 2 * ((units + 2 * ncu - 1) / (2 * ncu));
         if (one < two && lds < 84 * 1024) lds = 84 * 1024;
     }
-    if (!bus0) {
-        if (hipError_t e = lf_lds(k_lf_inv<R, C, COLS, false, true>, lds)) return e;
-        hipLaunchKernelGGL((k_lf_inv<R, C, COLS, false, true>), dim3(C / COLS, frames_run, njobs), block, lds, s, A, nframes, base, hop, mpad,
-                           nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab);
-    } else if (out) {
+    if (out) {
         if (hipError_t e = lf_lds(k_lf_inv<R, C, COLS, true, true>, lds)) return e;
-        hipLaunchKernelGGL((k_lf_inv<R, C, COLS, true, true>), dim3(C / COLS, frames_run, 2), block, lds, s, A, nframes, base, hop, mpad, nsrc,
-                           bus0, bus1, tl, vol, out, out_stride, out_len, tab);
+        hipLaunchKernelGGL((k_lf_inv<R, C, COLS, true, true>), dim3(C / COLS, frames_run, 2), block, lds, s, A, nframes, frame0, base, hop, mpad,
+                           nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab);
     } else {
         if (hipError_t e = lf_lds(k_lf_inv<R, C, COLS, true, false>, lds)) return e;
-        hipLaunchKernelGGL((k_lf_inv<R, C, COLS, true, false>), dim3(C / COLS, frames_run, 2), block, lds, s, A, nframes, base, hop, mpad, nsrc,
-                           bus0, bus1, tl, vol, out, out_stride, out_len, tab);
+        hipLaunchKernelGGL((k_lf_inv<R, C, COLS, true, false>), dim3(C / COLS, frames_run, 2), block, lds, s, A, nframes, frame0, base, hop, mpad,
+                           nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab);
     }
     return hipGetLastError();
 }
 
+template <int R, int C>
+static hipError_t lf_inv_t(const c32 *A, int nframes, int frame0, int frames_run, int njobs, int64_t base, int64_t hop, int64_t mpad, int nsrc,
+                           float *bus0, float *bus1, int64_t tl, const double *vol, float *out, int64_t out_stride, int64_t out_len,
+                           const c32 *tab, bool wide, hipStream_t s)
+{
+#ifndef WP_INVP_COLS
+#define WP_INVP_COLS 32
+#endif
+    if (!bus0) {  // the plain pass has registers to spare for larger workgroups: tiles of 32 columns (256-byte runs) for every frame size
+        constexpr int PC = WP_INVP_COLS * R / 16 > 1024 ? 1024 * 16 / R : WP_INVP_COLS;
+        const size_t ldsp = sizeof(c32) * R * PC;
+        if (hipError_t e = lf_lds(k_lf_inv<R, C, PC, false, true>, ldsp)) return e;
+        hipLaunchKernelGGL((k_lf_inv<R, C, PC, false, true>), dim3(C / PC, frames_run, njobs), dim3(PC * R / 16), ldsp, s, A, nframes, frame0, base,
+                           hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab);
+        return hipGetLastError();
+    }
+    if constexpr (R > 128) {
+        if (wide)
+            return lf_inv_fold_t<R, C, 32>(A, nframes, frame0, frames_run, base, hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab, s);
+        return lf_inv_fold_t<R, C, 16>(A, nframes, frame0, frames_run, base, hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab, s);
+    } else {
+        return lf_inv_fold_t<R, C, 32>(A, nframes, frame0, frames_run, base, hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab, s);
+    }
+}
+
 // bus0 == nullptr: plain results for every job; otherwise the bus fold over nsrc stereo sources,
-// with the per-job results too when out != nullptr
-hipError_t launch_lf_inv(int R, int C, const c32 *A, int nframes, int frames_run, int njobs, int64_t base, int64_t hop, int64_t mpad, int nsrc,
-                         float *bus0, float *bus1, int64_t tl, const double *vol, float *out, int64_t out_stride,
-                         int64_t out_len, const c32 *tab, hipStream_t s)
+// with the per-job results too when out != nullptr.  Frames [frame0, frame0 + frames_run) of the run.
+hipError_t launch_lf_inv(int R, int C, const c32 *A, int nframes, int frame0, int frames_run, int njobs, int64_t base, int64_t hop, int64_t mpad,
+                         int nsrc, float *bus0, float *bus1, int64_t tl, const double *vol, float *out, int64_t out_stride,
+                         int64_t out_len, const c32 *tab, bool wide, hipStream_t s)
 {
     if (frames_run <= 0) return hipSuccess;
     if (nframes > 65535 || njobs > 65535) return hipErrorInvalidValue;
     return lf_dispatch(R, C, [&](auto r, auto c) {
-        return lf_inv_t<int(r), int(c)>(A, nframes, frames_run, njobs, base, hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len, tab, s);
+        return lf_inv_t<int(r), int(c)>(A, nframes, frame0, frames_run, njobs, base, hop, mpad, nsrc, bus0, bus1, tl, vol, out, out_stride, out_len,
+                                        tab, wide, s);
     });
 }
 
