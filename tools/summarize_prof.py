@@ -15,7 +15,7 @@ def short(name):
     for k in ("k_lf_fwd", "k_lf_mid", "k_lf_inv", "k_fft_fwd", "k_fft_inv", "k_mac", "k_mix_prep", "k_mix", "k_hpack", "k_synth_noise"):
         if k in n:
             t = n[n.index(k):]
-            return t[:44]
+            return t[:52]
     return n[:40]
 
 
@@ -23,7 +23,7 @@ print("# kernel-trace stats")
 for f in sorted(glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True)):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            print("%-42s calls %6s  avg %10.1f us  total %10.1f us  %5s%%" % (
+            print("%-52s calls %6s  avg %10.1f us  total %10.1f us  %5s%%" % (
                 short(row["Name"]), row["Calls"], float(row["AverageNs"]) / 1e3, float(row["TotalDurationNs"]) / 1e3, row["Percentage"]))
 
 # The stats average above includes the warm-up launch(es), which run cold (first touch of the
@@ -40,7 +40,7 @@ for f in sorted(glob.glob(os.path.join(root, "stats", "**", "*kernel_trace.csv")
         if not any(t in k for t in ("k_lf_", "k_fft_fwd<", "k_fft_fwd_pair<", "k_fft_inv", "k_mac", "k_mix<")) or len(v) <= WARM:
             continue
         d = [x[1] for x in sorted(v)]
-        print("%-42s %s  -> steady avg %10.1f us" % (k, " ".join("%.0f" % x for x in d), sum(d[WARM:]) / len(d[WARM:])))
+        print("%-52s %s  -> steady avg %10.1f us" % (k, " ".join("%.0f" % x for x in d), sum(d[WARM:]) / len(d[WARM:])))
     # With several runs of frames a kernel is launched once per run and step (and k_lf_mid_jobs<8> lists a long and a
     # short launch alternately): per step, the launches of each kernel family added up.  A step starts at a launch of
     # the forward kernel with the longest average duration.
@@ -51,13 +51,14 @@ for f in sorted(glob.glob(os.path.join(root, "stats", "**", "*kernel_trace.csv")
         starts = sorted(x[0] for x in per[lead])
         if len(starts) > WARM:
             t0, nst = starts[WARM], len(starts) - WARM
-            print("# per step after the warm-up steps: launches of one kernel family added up (us)")
+            print("# per step after the warm-up steps: launches of one kernel family added up (us); inverse passes of different runs of frames")
+            print("# run on different streams and overlap: their durations add up to more than the pass takes (bench.py's roofline.kernel_ms has the pass)")
             sums = defaultdict(float)
             for k, v in per.items():
                 if any(t in k for t in ("k_lf_", "k_fft_fwd", "k_fft_inv", "k_mac", "k_mix<")):
                     sums[fam(k)] += sum(x[1] for x in v if x[0] >= t0)
             for k in sorted(sums):
-                print("%-42s %10.1f us per step" % (k, sums[k] / nst))
+                print("%-52s %10.1f us per step" % (k, sums[k] / nst))
 
 print("# PMC (per launch averages)")
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
@@ -90,8 +91,8 @@ for k in acc:
         base = "k_fft_fwd"
     if base == "k_fft_inv_mix":
         base = "k_fft_inv_mix_w" if "true" in k else "k_fft_inv_mix"
-    if base == "k_lf_inv":  # k_lf_inv<R, COLS, MIX, WRITE>
-        flags = k.replace(" ", "").split(",")[2:4]
+    if base == "k_lf_inv":  # k_lf_inv<R, C, COLS, MIX, WRITE>
+        flags = k.replace(" ", "").split(",")[3:5]
         base = "k_lf_inv" + ("_mix" if flags and flags[0].startswith("true") else "") + ("_w" if len(flags) > 1 and flags[0].startswith("true") and flags[1].startswith("true") else "")
     if k.startswith("k_lf_mid<true"):
         continue  # the one-off kernel-spectrum launch
