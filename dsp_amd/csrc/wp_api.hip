@@ -14,6 +14,7 @@
 #include <initializer_list>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <tuple>
 #include <utility>
@@ -2056,6 +2057,7 @@ struct wp_buf {
     float *p;
     size_t bytes;
     int refs;
+    bool carved;  // part of a slab: goes back to the pool whatever its cap, never to hipFree
 };
 
 static std::mutex g_buf_mu;
@@ -2063,6 +2065,17 @@ static std::map<uint64_t, wp_buf *> g_bufs;
 static uint64_t g_next_buf_id = 1;
 static std::multimap<std::pair<int, size_t>, void *> g_pool;  // (device, bytes) -> free allocation
 static size_t g_pool_bytes = 0;
+
+// Buffers of up to SLAB_MAX bytes that the pool cannot serve are carved from slabs of SLAB_BYTES (one hipMalloc per
+// slab, kept until the process ends).  A block loop that asks for a fresh result buffer per block while its garbage
+// collector has not yet given the earlier ones back then pays no hipMalloc per block (about 40 us each).
+struct Slab {
+    char *p = nullptr;
+    size_t used = 0, size = 0;
+};
+static std::map<int, Slab> g_slab;  // per device, under g_buf_mu
+static std::set<void *> g_carved;   // blocks carved from slabs (live or pooled)
+constexpr size_t SLAB_BYTES = (size_t)64 << 20, SLAB_MAX = (size_t)8 << 20;
 
 static size_t pool_limit()
 {
@@ -2085,6 +2098,8 @@ extern "C" wp_buf *wp_buf_create(int nch, int64_t frames)
     const int64_t stride = (frames + 63) & ~(int64_t)63;
     size_t bytes = sizeof(float) * (size_t)nch * (size_t)(stride > 0 ? stride : 64);
     void *p = nullptr;
+    bool carved = false;
+    hipError_t e = hipSuccess;
     {
         std::lock_guard<std::mutex> lk(g_buf_mu);
         auto it = g_pool.find(std::make_pair(dev, bytes));
@@ -2092,18 +2107,36 @@ extern "C" wp_buf *wp_buf_create(int nch, int64_t frames)
             p = it->second;
             g_pool.erase(it);
             g_pool_bytes -= bytes;
+            carved = g_carved.count(p) != 0;
+        } else if (bytes <= SLAB_MAX && pool_limit() > 0) {
+            Slab &sl = g_slab[dev];
+            if (sl.size - sl.used < bytes) {  // (what is left of the old slab stays unused)
+                void *q = nullptr;
+                e = hipMalloc(&q, SLAB_BYTES);
+                if (e == hipSuccess) {
+                    sl.p = (char *)q;
+                    sl.used = 0;
+                    sl.size = SLAB_BYTES;
+                }
+            }
+            if (e == hipSuccess) {
+                p = sl.p + sl.used;
+                sl.used += bytes;  // a multiple of 256
+                carved = true;
+                g_carved.insert(p);
+            }
         }
     }
-    hipError_t e = hipSuccess;
-    if (!p) e = hipMalloc(&p, bytes);
+    if (!p && e == hipSuccess) e = hipMalloc(&p, bytes);
     // a fresh typed array is zero-filled; stream order keeps this ahead of any later use
     if (e == hipSuccess) e = hipMemsetAsync(p, 0, bytes, nullptr);
     if (e != hipSuccess) {
         fail(WP_ERR_HIP, "wp_buf_create: %zu bytes: %s", bytes, hipGetErrorString(e));
-        if (p) (void)hipFree(p);
+        if (p && !carved) (void)hipFree(p);
         return nullptr;
     }
     wp_buf *b = new wp_buf();
+    b->carved = carved;
     b->dev = dev;
     b->nch = nch;
     b->frames = frames;
@@ -2139,7 +2172,7 @@ extern "C" void wp_buf_release(wp_buf *b)
         std::lock_guard<std::mutex> lk(g_buf_mu);
         if (--b->refs > 0) return;
         g_bufs.erase(b->id);
-        if (g_pool_bytes + b->bytes <= pool_limit()) {
+        if (b->carved || g_pool_bytes + b->bytes <= pool_limit()) {
             g_pool.emplace(std::make_pair(b->dev, b->bytes), b->p);
             g_pool_bytes += b->bytes;
         } else {

@@ -23,16 +23,21 @@ const clampIndex = (i, n) => {
   return Math.min(i, n)
 }
 
+// key of the native handle: a symbol-keyed property is an ordinary fast property for the
+// constructor, and a structured clone (which copies own string-keyed properties only)
+// carries just the numbers
+const HANDLE = Symbol('wpdsp handle')
+
 export class DeviceChannel {
   constructor (h, wpbuf, ch, off, length) {
-    // native handle (keeps the device memory alive); not enumerable, so a structured
-    // clone carries only the numbers below
-    Object.defineProperty(this, 'h', { value: h })
+    this[HANDLE] = h // native handle (keeps the device memory alive)
     this.wpbuf = wpbuf // process-wide buffer id
     this.ch = ch
     this.off = off
     this.length = length
   }
+
+  get h () { return this[HANDLE] }
 
   get byteOffset () { return this.off * 4 }
   get byteLength () { return this.length * 4 }
