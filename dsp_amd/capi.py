@@ -85,6 +85,7 @@ PROTOTYPES = {
     "wp_host_pin": (C.c_int, [C.c_void_p, C.c_size_t]),
     "wp_host_unpin": (C.c_int, [C.c_void_p]),
     "wp_lf_cover": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
+    "wp_lf_wide_frames": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "wp_bus_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "wp_bus_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "wp_buf_create": (C.c_void_p, [C.c_int, C.c_int64]),

@@ -1176,6 +1176,13 @@ static int lf_wide_frames(int C, int fr, int ncu)
     return best;
 }
 
+extern "C" int wp_lf_wide_frames(int columns, int frames, int compute_units)
+{
+    if ((columns != LF_C && columns != LF_C_BIG) || frames < 0 || frames > 65535 || compute_units < 1 || compute_units > 4096)
+        return fail(WP_ERR_INVALID, "wp_lf_wide_frames: bad argument");
+    return lf_wide_frames(columns, frames, compute_units);
+}
+
 // Inverse passes of every run of frames.  The runs write disjoint sample ranges; every run after the first goes
 // to a side stream of its own, so that all of them overlap the first run's pass.  A bus-fold workgroup is a serial
 // chain over the sources; a run with too few tiles to give every CU one (the short runs at the end of a cover) would

@@ -84,6 +84,12 @@ int64_t wp_ir_info(const wp_ir *ir, int which);
  * partitioned form) and writes, per run, frame length in samples, frames per job, samples a frame
  * advances by, first output sample into runs[4*i .. 4*i+3] (room for 3 runs). */
 int wp_lf_cover(int64_t L, int64_t M, int nch, int64_t *runs /* 12 */);
+/* Host only: of the `frames` frames (256 rows of `columns` = 2048 or 4096 points) that a batched one-pass call
+ * (wp_conv_run_mix_dev: every go() result of lib/convolve.js:564-586 written and src/mix-buffers.js:49-52
+ * folded in the same pass) runs of a plan's first run of frames, how many take bus-fold workgroups over tiles
+ * of 32 columns instead of 16 on a device of `compute_units` CUs, under the current WP_TUNE_LF_WIDE setting.
+ * Results do not depend on it. */
+int wp_lf_wide_frames(int columns, int frames, int compute_units);
 
 /* ---- convolution: lib/convolve.js:564-586 fftConvolution(...) -> go(input) - */
 /* One go(input): ch picks the IR channel; in_len <= reference FFT length, else

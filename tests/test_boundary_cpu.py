@@ -217,3 +217,26 @@ def test_long_frame_cover_search_is_host_only_and_consistent():
             assert [f for f, _, _, _ in runs] == sorted((f for f, _, _, _ in runs), reverse=True)
     finally:
         lib.wp_tune(5, 0)
+
+
+def test_wide_chain_schedule_is_host_logic():
+    """wp_lf_wide_frames (no GPU needed): how many frames of a run's bus-fold pass take the wide tiles.  A wide
+    chain costs 1.5 narrow ones and has a CU to itself; the split with the shortest schedule wins, ties go wide."""
+    from dsp_amd import capi
+    lib = capi.lib()
+    # the 60 s render with a 2 s response: three frames of 2^20 samples on 256 CUs -> two wide (256 chains, one
+    # round) and one narrow (256 chains); all three wide would leave half the chip idle in a second round
+    assert lib.wp_lf_wide_frames(2048, 3, 256) == 2
+    assert lib.wp_lf_wide_frames(2048, 2, 256) == 2
+    assert lib.wp_lf_wide_frames(2048, 1, 256) == 0      # 128 wide chains on 256 CUs: 1.5 against 1.0 for 256 narrow ones
+    assert lib.wp_lf_wide_frames(4096, 1, 256) == 1      # one frame of 2^21 samples: 256 wide chains, one round
+    assert lib.wp_lf_wide_frames(2048, 0, 256) == 0
+    assert lib.wp_lf_wide_frames(2048, 4, 256) == 4      # 512 wide chains: two full rounds (3.0) against 4.0
+    capi.check(lib.wp_tune(13, 1), "wp_tune")
+    try:
+        assert lib.wp_lf_wide_frames(2048, 3, 256) == 0
+        capi.check(lib.wp_tune(13, 2), "wp_tune")
+        assert lib.wp_lf_wide_frames(2048, 3, 256) == 3
+    finally:
+        lib.wp_tune(13, 0)
+    assert lib.wp_lf_wide_frames(1024, 3, 256) == capi.WP_ERR_INVALID

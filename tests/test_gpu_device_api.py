@@ -609,6 +609,19 @@ def test_long_frame_batch_row_pass_vs_oracle(torch, oracle, own_ir, L, M, frame0
             lib.wp_tune(12, 0)
         assert torch.equal(b2.view(torch.int32), bus.view(torch.int32)), how
         assert torch.equal(o2.view(torch.int32), out.view(torch.int32)), how
+    # bus-fold workgroups of 256-row frames over tiles of 16 columns only / of 32 only (WP_TUNE_LF_WIDE 1 / 2; the
+    # library schedules a split): a column's transform does not depend on its tile, so again the same bits
+    for how in (1, 2):
+        capi.check(lib.wp_tune(13, how), "wp_tune")
+        try:
+            b2 = torch.zeros((2, L), dtype=torch.float32, device="cuda")
+            o2 = torch.empty((njobs, L + M), dtype=torch.float32, device="cuda")
+            conv.run_and_mix(xd, o2, [b2[0], b2[1]], vol)
+            torch.cuda.synchronize()
+        finally:
+            lib.wp_tune(13, 0)
+        assert torch.equal(b2.view(torch.int32), bus.view(torch.int32)), ("tile width", how)
+        assert torch.equal(o2.view(torch.int32), out.view(torch.int32)), ("tile width", how)
 
 
 def test_long_frame_edge_cases(torch, oracle):
