@@ -366,7 +366,7 @@ double wp_bpm_from_beat_rate(double sample_rate, int64_t beat_rate);
 #define WP_TUNE_LF_SPLIT 12 /* long-frame form, one-pass results + bus: 1 = every run of frames folds the bus inside its inverse pass, 2 = every run after the first takes the plain pass + the mix kernel over its range, 0 = the later runs fold in their pass while the chip has room for their workgroups beside the first run's (takes effect at once) */
 #define WP_TUNE_LF_WIDE 13 /* long-frame form, results + bus in one pass, frames of 256 rows: 1 = bus-fold chains over tiles of 16 columns only, 2 = of 32 columns only, 0 = the split with the shortest schedule (takes effect at once) */
 #define WP_TUNE_FWD_FORM 4  /* forward transform: 1 one segment per workgroup, 2 two (the default; takes effect at once) */
-#define WP_TUNE_POOL_MB 3   /* cap of the wp_buf recycling pool in MiB (default 2048; 0 disables it) */
+#define WP_TUNE_POOL_MB 3   /* cap of the wp_buf recycling pool in MiB (default 2048; 0 disables it and the 64 MiB slabs that buffers of up to 8 MiB are carved from when the pool has none of their size; carved memory stays with the process) */
 int wp_tune(int what, int64_t value);
 
 /* ---- synthetic inputs for tests and benchmarks (no reference counterpart) --- */
