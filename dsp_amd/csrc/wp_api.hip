@@ -1200,6 +1200,7 @@ static int conv_back_lf(wp_conv *c, int64_t limit, int nsrc, float *bus0, float 
     const int ncu = device_cus();
     int64_t room = 2 * (int64_t)ncu;
     int wide0 = 0;  // frames of run 0 whose chains take the wide tiles
+    // (the bus-only pass keeps the narrow chains, two per CU: on wide tiles it measured 2.11 against 1.72 ms)
     if (bus0 && out_dev && ir->lf.nseg > 0) {
         const LfSeg &g0 = ir->lf.seg[0];
         const int fr0 = lf_frames_run(g0, limit);
