@@ -111,11 +111,13 @@ __global__ __launch_bounds__(COLS *R / 16) void k_lf_fwd(const float *__restrict
         const c32 f = cmul(tab[LF_ROW + j], tab[LF_COL + c]);
         static_for<0, PT>([&](auto t) { v[t] = cmul(v[t], mul_w32<int(t), false>(f)); });
     }
+#if !defined(WP_FWD_ABLATE)  // (measurement builds: the samples go out as they came in, through the same loads and stores)
     stage_compute<R, 0, false>(j, v, tw);
     stage_store<R, 0, false>(j, v, [&](int i, c32 val, int, int) { lds[i * COLS + col] = val; });
     __syncthreads();
     stage_load<R, 1>(j, v, [&](int i) { return lds[i * COLS + col]; });
     stage_compute<R, 1, false>(j, v, tw);
+#endif
     // outputs k1 = j' + 16*t (j' = j + u*NTF), times exp(-2*pi*i*c*k1/Nc) = W^(c*j') * (W^(16c))^t
     constexpr int R1 = FftPlan<R>::radix(1), NB = PT / R1;
     c32 pw[R1], wj[NB];

@@ -14,7 +14,7 @@ else
   (cd "$ROOT" && git archive "$REF" dsp_amd/csrc include) | tar -x -C "$W"
 fi
 rm -rf "$W/dsp_amd/csrc/build"; mkdir -p "$W/dsp_amd/lib"
-make -C "$W/dsp_amd/csrc" -j4 CXXFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $*" >/dev/null
+make -C "$W/dsp_amd/csrc" -j4 CXXFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable $*" >/dev/null
 cp "$W/dsp_amd/lib/libwpdsp.so" "$ROOT/variants/$NAME/libwpdsp.so"
 rm -rf "$W"
 echo "variants/$NAME/libwpdsp.so"
