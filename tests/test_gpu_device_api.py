@@ -200,6 +200,44 @@ def test_ir_spectra_are_shared_between_handles(torch, oracle):
     lib.wp_ir_destroy(c)
 
 
+def test_device_buffers_that_miss_the_pool_are_carved_apart(torch):
+    """A block loop whose host releases nothing for a while asks for a fresh result buffer per block
+    (lib/convolve.js:575,582 allocate per call): buffers the pool cannot serve are carved from slabs.  Forty
+    live buffers of 1.5 MB (more than one 64 MiB slab's worth) must not overlap, must come zero-filled, and
+    must come back from the pool once released; a buffer too large for the slabs still works."""
+    from dsp_amd import capi
+    lib = capi.lib()
+    f32p = C.POINTER(C.c_float)
+    frames, n = 190016, 48  # (a size no other test uses: the pool holds none of it)
+    bufs = [capi.check_handle(lib.wp_buf_create(2, frames), "wp_buf_create") for _ in range(n)]
+    spans = sorted((lib.wp_buf_channel(b, 0), lib.wp_buf_info(b, 4)) for b in bufs)
+    for (p0, b0), (p1, _) in zip(spans, spans[1:]):
+        assert p0 + b0 <= p1, "buffers overlap"
+    pat = np.arange(16, dtype=np.float32) + 1
+    for i, b in enumerate(bufs):
+        out = np.empty(16, np.float32)
+        capi.check(lib.wp_buf_read(b, 1, frames - 16, out.ctypes.data_as(f32p), 16), "wp_buf_read")
+        assert not out.any(), "a fresh buffer is zero-filled"
+        capi.check(lib.wp_buf_write(b, 1, frames - 16, (pat * (i + 1)).ctypes.data_as(f32p), 16), "wp_buf_write")
+    for i, b in enumerate(bufs):  # nobody wrote into a neighbour
+        out = np.empty(16, np.float32)
+        capi.check(lib.wp_buf_read(b, 1, frames - 16, out.ctypes.data_as(f32p), 16), "wp_buf_read")
+        assert np.array_equal(out, pat * (i + 1))
+    first = {lib.wp_buf_channel(b, 0) for b in bufs}
+    for b in bufs:
+        lib.wp_buf_release(b)
+    again = [capi.check_handle(lib.wp_buf_create(2, frames), "wp_buf_create") for _ in range(n)]
+    assert {lib.wp_buf_channel(b, 0) for b in again} == first, "released buffers come back from the pool"
+    for b in again:
+        out = np.empty(16, np.float32)
+        capi.check(lib.wp_buf_read(b, 1, frames - 16, out.ctypes.data_as(f32p), 16), "wp_buf_read")
+        assert not out.any(), "a recycled buffer is zero-filled again"
+        lib.wp_buf_release(b)
+    big = capi.check_handle(lib.wp_buf_create(2, 3000000), "wp_buf_create")  # 24 MB: its own allocation
+    assert lib.wp_buf_info(big, 4) >= 24000000
+    lib.wp_buf_release(big)
+
+
 def test_device_buffers_c_abi_reverb_to_mix_chain(torch, oracle):
     """wp_buf + wp_reverb_block_to + wp_mix_dev: a stereo bar goes upload -> block reverb (result in
     a fresh wp_buf per block, carried tail read from the previous one) -> mixed into a device bus,
