@@ -15,5 +15,5 @@ for line in sys.stdin:
 for r in rows:
     n=subprocess.run(["c++filt",r["name"]],capture_output=True,text=True).stdout.strip()
     n=re.sub(r"\(.*","",n)
-    print("%-42s vgpr %-4s agpr %-3s sgpr %-4s scratch %-5s lds %-6s occ %s" % (n[:42], r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"), r.get("ScratchSize [bytes/lane]"), r.get("LDS Size [bytes/block]"), r.get("Occupancy [waves/SIMD]")))
+    print("%-58s vgpr %-4s agpr %-3s sgpr %-4s scratch %-5s lds %-6s occ %s" % (n[:58], r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"), r.get("ScratchSize [bytes/lane]"), r.get("LDS Size [bytes/block]"), r.get("Occupancy [waves/SIMD]")))
 '
