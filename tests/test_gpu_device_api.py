@@ -662,6 +662,59 @@ def test_long_frame_batch_row_pass_vs_oracle(torch, oracle, own_ir, L, M, frame0
         assert torch.equal(o2.view(torch.int32), out.view(torch.int32)), ("tile width", how)
 
 
+def test_long_frame_wide_and_narrow_chains_of_one_run(torch, oracle):
+    """Three frames of 2^20 samples per job (the 60 s render's first run of frames): on 256 CUs the bus-fold pass
+    takes tiles of 32 columns for the first two frames and of 16 columns, in a launch that starts at frame 2, for
+    the third.  Every job against the oracle, the bus over all three frames against the oracle's mixBuffers of
+    its results (src/mix-buffers.js:49-52), and bit for bit against the pass on narrow tiles only."""
+    from dsp_amd import capi, device
+    lib = capi.lib()
+    L, M, njobs = 2300000, 96000, 16
+    irs = np.stack([oracle.synth_ir(M, 760 + c) for c in range(2)])
+    for knob, val in ((5, 2), (9, 20), (6, 1)):  # long-frame form, frames of at most 2^20 samples, one run of frames
+        capi.check(lib.wp_tune(knob, val), "wp_tune")
+    try:
+        ir = device.DeviceIR(torch.from_numpy(irs).cuda(), L)
+    finally:
+        for knob in (5, 9, 6):
+            lib.wp_tune(knob, 0)
+    job_ch = [j % 2 for j in range(njobs)]
+    conv = device.BatchedConvolver(ir, job_ch)
+    assert lib.wp_conv_info(conv.handle, 6) == 1 and lib.wp_conv_info(conv.handle, 10) == 1
+    assert lib.wp_conv_info(conv.handle, 16) == 1048576 and lib.wp_conv_info(conv.handle, 17) == 3
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    wide = lib.wp_lf_wide_frames(2048, 3, cus)
+    x = np.stack([oracle.synth_noise(L, 1300 + j) for j in range(njobs)])
+    xd = torch.from_numpy(x).cuda()
+    tracks = njobs // 2
+    vol = [0.8 / (s + 1.5) for s in range(tracks)]
+    out = torch.empty((njobs, L + M), dtype=torch.float32, device="cuda")
+    bus = torch.zeros((2, L), dtype=torch.float32, device="cuda")
+    conv.run_and_mix(xd, out, [bus[0], bus[1]], vol)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    kern = [oracle.fft_process_kernel(L, irs[c]) for c in range(2)]
+    want = [oracle.fft_convolution(L, kern[job_ch[j]], M)(x[j]) for j in range(njobs)]
+    for j in range(njobs):
+        assert float(np.abs(got[j].astype(np.float64) - want[j]).max()) <= TOL, j
+    want_bus = [np.zeros(L, np.float32), np.zeros(L, np.float32)]
+    oracle.mix_buffers(want_bus, *[[[want[2 * s][:L], want[2 * s + 1][:L]], 1, vol[s], 0] for s in range(tracks)])
+    for ch in range(2):
+        assert float(np.abs(bus[ch].cpu().numpy().astype(np.float64) - want_bus[ch]).max()) <= TOL, ch
+    for how in (1, 2):  # narrow tiles only, wide tiles only
+        capi.check(lib.wp_tune(13, how), "wp_tune")
+        try:
+            b2 = torch.zeros((2, L), dtype=torch.float32, device="cuda")
+            o2 = torch.empty((njobs, L + M), dtype=torch.float32, device="cuda")
+            conv.run_and_mix(xd, o2, [b2[0], b2[1]], vol)
+            torch.cuda.synchronize()
+        finally:
+            lib.wp_tune(13, 0)
+        assert torch.equal(b2.view(torch.int32), bus.view(torch.int32)), (how, wide)
+        assert torch.equal(o2.view(torch.int32), out.view(torch.int32)), (how, wide)
+    assert 0 <= wide <= 3 and (cus != 256 or wide == 2)
+
+
 def test_long_frame_edge_cases(torch, oracle):
     """Long-frame plans at the edges the partitioned form is tested at: no input at all (zeros), a carried tail
     added to the head of the results (lib/impulse-reverb.js:14-16), a bus shorter than the first run of frames
