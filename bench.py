@@ -331,10 +331,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def time_steps(step, warmup, steps):
+    def time_steps(step, warmup, steps, after_warmup=None):
         for _ in range(warmup):
             step(False)
         fence()
+        if after_warmup is not None:
+            after_warmup()
         t0 = time.perf_counter()
         for _ in range(steps):
             step(True)
@@ -403,20 +405,18 @@ def main():
             mix.run([bus[0], bus[1]])
             ev[1].record()
         reduce_bus(k)
-        if timed and which == "main":
-            f, m, i = conv.profile_read()
-            kern_ms[k1n] += f
-            kern_ms[k2n] += m
-            if fused:
-                kern_ms[k3n + "_mix"] += i
-            elif onepass:
-                kern_ms[k3n + "_mix_w"] += i
-            else:
-                ev[1].synchronize()
-                kern_ms[k3n] += i
-                kern_ms["k_mix"] += ev[0].elapsed_time(ev[1])
+        if timed and which == "main" and not fused and not onepass:
+            ev[1].synchronize()  # (two-pass path only: the mix kernel between torch events)
+            kern_ms["k_mix"] += ev[0].elapsed_time(ev[1])
 
-    dt = time_steps(step, a.warmup, a.steps)
+    # the library's events of the K timed steps are added up after the timed region (wp_conv_profile_sum): no step
+    # waits for the one before it
+    dt = time_steps(step, a.warmup, a.steps, after_warmup=conv.profile_sum)
+    (f, m, i), nruns_prof = conv.profile_sum()
+    assert nruns_prof == a.steps, "profiled runs %d != timed steps %d" % (nruns_prof, a.steps)
+    kern_ms[k1n] += f
+    kern_ms[k2n] += m
+    kern_ms[(k3n + "_mix") if fused else (k3n + "_mix_w") if onepass else k3n] += i
 
     # secondary measurement, outside the headline's timed region: the fused reverb+mix path
     fused_extra = None
@@ -450,10 +450,8 @@ def main():
         def stepp(timed):
             buses[0].zero_()
             convp.run_and_mix(x, out, [buses[0][0], buses[0][1]], vol)
-            if timed:
-                for i, v in enumerate(convp.profile_read()):
-                    pk[i] += v
-        pdt = time_steps(stepp, 1, a.steps)
+        pdt = time_steps(stepp, 1, a.steps, after_warmup=convp.profile_sum)
+        pk = list(convp.profile_sum()[0])
         Bp, Tp = int(capi.lib().wp_conv_info(convp.handle, 2)), int(capi.lib().wp_conv_info(convp.handle, 1))
         Tinp = min(Tp, (F + Bp - 1) // Bp + 1)
         mac_bytes = njobs * 8 * Bp * (Tinp + Tp)

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "wp_conv_workspace_bytes": (C.c_int64, [C.c_void_p]),
     "wp_conv_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "wp_conv_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "wp_conv_profile_sum": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "wp_conv_info": (C.c_int64, [C.c_void_p, C.c_int]),
     "wp_reverb_view_for": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(WpReverbView)]),
     "wp_reverb_create": (C.c_void_p, [C.c_void_p, C.c_int, i32p, C.c_int64]),

@@ -506,7 +506,15 @@ struct wp_conv {
     int64_t bytes;
     bool prof;
     bool prof_valid;
-    hipEvent_t ev[4];
+    hipEvent_t ev[4];  // the set of the current (last) profiled run: one of evr's
+    // profiled runs rotate through PROF_RING sets of four events, so that a caller can time many runs back to back and
+    // add them up afterwards (wp_conv_profile_sum) instead of waiting for every run before it queues the next
+    static constexpr int PROF_RING = 32;
+    hipEvent_t evr[PROF_RING][4];
+    bool ev_used[PROF_RING];  // recorded, not yet added to prof_sum
+    int ev_cur;
+    double prof_sum[3];
+    int prof_runs;
     double *vol_dev;    // per-source gains of the fused reverb+mix call
     std::vector<double> vol_host;  // what vol_dev holds (an unchanged gain table is not uploaded again)
 };
@@ -890,6 +898,12 @@ static void plan_geometry(wp_conv *c, wp_ir *ir, int njobs, int64_t out_len)
     c->bytes = 0;
     c->prof = c->prof_valid = false;
     for (auto &e : c->ev) e = nullptr;
+    for (auto &set : c->evr)
+        for (auto &e : set) e = nullptr;
+    for (auto &u : c->ev_used) u = false;
+    c->ev_cur = 0;
+    c->prof_sum[0] = c->prof_sum[1] = c->prof_sum[2] = 0.0;
+    c->prof_runs = 0;
     c->vol_dev = nullptr;
     c->last_stream = nullptr;
     c->used = false;
@@ -961,8 +975,9 @@ extern "C" void wp_conv_destroy(wp_conv *c)
         if (c->mix_dev[i]) (void)hipFree(c->mix_dev[i]);
         if (c->mix_pin[i]) (void)hipHostFree(c->mix_pin[i]);
     }
-    for (auto &e : c->ev)
-        if (e) (void)hipEventDestroy(e);
+    for (auto &set : c->evr)
+        for (auto &e : set)
+            if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -1020,10 +1035,59 @@ extern "C" int wp_conv_profile(wp_conv *c, int enable)
 {
     if (int rc = need_device()) return rc;
     if (!c) return fail(WP_ERR_INVALID, "wp_conv_profile: null plan");
-    if (enable && !c->ev[0])
-        for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
+    if (enable && !c->evr[0][0]) {
+        for (auto &set : c->evr)
+            for (auto &e : set) HIPCHK(hipEventCreate(&e));
+        for (int i = 0; i < 4; i++) c->ev[i] = c->evr[0][i];
+    }
     c->prof = enable != 0;
     c->prof_valid = false;
+    return WP_OK;
+}
+
+// adds a recorded set's three durations to the sums (waits for the set's last event: it was recorded PROF_RING runs ago
+// when this is called from prof_begin)
+static int prof_flush(wp_conv *c, int k)
+{
+    if (!c->ev_used[k]) return WP_OK;
+    HIPCHK(hipEventSynchronize(c->evr[k][3]));
+    for (int i = 0; i < 3; i++) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c->evr[k][i], c->evr[k][i + 1]));
+        c->prof_sum[i] += ms;
+    }
+    c->prof_runs++;
+    c->ev_used[k] = false;
+    return WP_OK;
+}
+// a profiled run takes the next set of events
+static int prof_begin(wp_conv *c)
+{
+    if (!c->prof) return WP_OK;
+    c->ev_cur = (c->ev_cur + 1) % wp_conv::PROF_RING;
+    if (int rc = prof_flush(c, c->ev_cur)) return rc;
+    for (int i = 0; i < 4; i++) c->ev[i] = c->evr[c->ev_cur][i];
+    return WP_OK;
+}
+static void prof_end(wp_conv *c)
+{
+    c->ev_used[c->ev_cur] = true;
+    c->prof_valid = true;
+}
+
+extern "C" int wp_conv_profile_sum(wp_conv *c, double *ms3_sum, int *runs)
+{
+    if (int rc = need_device()) return rc;
+    if (!c || !ms3_sum || !runs) return fail(WP_ERR_INVALID, "wp_conv_profile_sum: null argument");
+    if (!c->evr[0][0]) return fail(WP_ERR_INVALID, "wp_conv_profile_sum: profiling was never enabled on this plan");
+    for (int k = 1; k <= wp_conv::PROF_RING; k++)  // oldest first
+        if (int rc = prof_flush(c, (c->ev_cur + k) % wp_conv::PROF_RING)) return rc;
+    for (int i = 0; i < 3; i++) {
+        ms3_sum[i] = c->prof_sum[i];
+        c->prof_sum[i] = 0.0;
+    }
+    *runs = c->prof_runs;
+    c->prof_runs = 0;
     return WP_OK;
 }
 
@@ -1072,6 +1136,7 @@ static c32 *lf_seg_A(const wp_conv *c, int i)
 static int conv_front_lf(wp_conv *c, const float *in_dev, int64_t in_stride, int64_t in_len, int64_t limit, hipStream_t s)
 {
     const wp_ir *ir = c->ir;
+    if (int rc = prof_begin(c)) return rc;
     if (c->prof) HIPCHK(hipEventRecord(c->ev[0], s));
     for (int i = 0; i < ir->lf.nseg; i++) {
         const LfSeg &g = ir->lf.seg[i];
@@ -1279,6 +1344,7 @@ static int conv_front(wp_conv *c, const float *in_dev, int64_t in_stride, int64_
     int Tin = (int)((in_len + B - 1) / B) + 1;
     if (Tin > Tout) Tin = Tout;  // later input blocks cannot reach the requested outputs
     if (in_len == 0) Tin = 0;
+    if (int rc = prof_begin(c)) return rc;
     if (c->prof) HIPCHK(hipEventRecord(c->ev[0], s));
     if (Tin > 0) HIPCHK(launch_fft_fwd(B, false, in_dev, in_stride, in_len, c->Z, T, Tin, c->njobs, ir->tables, s));
     if (c->prof) HIPCHK(hipEventRecord(c->ev[1], s));
@@ -1316,7 +1382,7 @@ extern "C" int wp_conv_run_dev(wp_conv *c, const float *in_dev, int64_t in_strid
     }
     if (c->prof) {
         HIPCHK(hipEventRecord(c->ev[3], s));
-        c->prof_valid = true;
+        prof_end(c);
     }
     return plan_leave(c, s);
 }
@@ -1357,7 +1423,7 @@ static int conv_mix_common(wp_conv *c, const float *in_dev, int64_t in_stride, i
     }
     if (c->prof) {
         HIPCHK(hipEventRecord(c->ev[3], s));
-        c->prof_valid = true;
+        prof_end(c);
     }
     return plan_leave(c, s);
 }

@@ -113,6 +113,14 @@ class BatchedConvolver:
         capi.check(capi.lib().wp_conv_profile_read(self.handle, ms), "wp_conv_profile_read")
         return tuple(float(v) for v in ms)
 
+    def profile_sum(self):
+        """((fwd_ms, mac_ms, inv_ms) added up, runs) over every profiled run since the last call of this
+        (synchronises once; the runs themselves are queued without a wait between them)."""
+        ms = (C.c_double * 3)()
+        runs = C.c_int(0)
+        capi.check(capi.lib().wp_conv_profile_sum(self.handle, ms, C.byref(runs)), "wp_conv_profile_sum")
+        return tuple(float(v) for v in ms), int(runs.value)
+
     def close(self):
         if getattr(self, "handle", None):
             capi.lib().wp_conv_destroy(self.handle)

@@ -164,12 +164,17 @@ int wp_conv_run_mix_dev(wp_conv *c, const float *in_dev, int64_t in_stride, int6
                         int64_t out_stride, float *const *tgt_dev, int64_t tl, const double *vol, void *stream);
 /* Device bytes of workspace a wp_conv holds. */
 int64_t wp_conv_workspace_bytes(const wp_conv *c);
-/* Measurement hook (no reference counterpart): when enabled, wp_conv_run_dev
- * brackets each of its three kernels (forward FFT, spectral MAC, inverse FFT)
- * with HIP events on the caller's stream; wp_conv_profile_read waits for the
- * last run and returns the three durations in milliseconds. */
+/* Measurement hook (no reference counterpart): when enabled, the wp_conv_*run*_dev
+ * calls bracket each of their three passes (forward transforms, spectral product,
+ * inverse transforms) with HIP events on the caller's stream.  wp_conv_profile_read
+ * waits for the last run and returns its three durations in milliseconds.
+ * wp_conv_profile_sum waits for every profiled run since the previous call of it,
+ * returns the three durations added up over those runs and how many they were, and
+ * starts a new sum: the runs can be queued back to back without a wait between them
+ * (the events rotate through 32 sets; a set that comes round again is added up first). */
 int wp_conv_profile(wp_conv *c, int enable);
 int wp_conv_profile_read(wp_conv *c, float *ms3);
+int wp_conv_profile_sum(wp_conv *c, double *ms3_sum, int *runs);
 /* Geometry of a plan: which = 0 jobs, 1 output blocks T, 2 partition size B,
  * 3 partitions P (padded), 4 blocks per MAC time chunk, 5 whether the small-batch
  * (gather) form of the spectral multiply-accumulate is in use, 6 whether the plan
