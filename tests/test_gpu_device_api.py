@@ -662,6 +662,32 @@ def test_long_frame_batch_row_pass_vs_oracle(torch, oracle, own_ir, L, M, frame0
         assert torch.equal(o2.view(torch.int32), out.view(torch.int32)), ("tile width", how)
 
 
+def test_profile_sum_counts_every_run(torch, oracle):
+    """wp_conv_profile_sum: the three pass durations added up over runs queued back to back, more of them than the
+    library keeps event sets for, and a fresh sum after every call; wp_conv_profile_read still returns the last run."""
+    from dsp_amd import capi, device
+    L, M, njobs = 20000, 3000, 4
+    irs = np.stack([oracle.synth_ir(M, 770 + c) for c in range(2)])
+    ir = device.DeviceIR(torch.from_numpy(irs).cuda(), L)
+    conv = device.BatchedConvolver(ir, [0, 1, 0, 1])
+    x = torch.from_numpy(np.stack([oracle.synth_noise(L, 1400 + j) for j in range(njobs)])).cuda()
+    out = torch.empty((njobs, L + M), dtype=torch.float32, device="cuda")
+    conv.profile(True)
+    for _ in range(3):
+        conv.run(x, out)
+    ms, runs = conv.profile_sum()
+    assert runs == 3 and all(v > 0 for v in ms)
+    for _ in range(75):
+        conv.run(x, out)
+    last = conv.profile_read()
+    ms, runs = conv.profile_sum()
+    assert runs == 75 and all(v > 0 for v in ms) and all(v > 0 for v in last)
+    assert sum(last) < sum(ms)
+    assert conv.profile_sum() == ((0.0, 0.0, 0.0), 0)
+    want = oracle.fft_convolution(L, oracle.fft_process_kernel(L, irs[1]), M)(x[3].cpu().numpy())
+    assert float(np.abs(out[3].cpu().numpy().astype(np.float64) - want).max()) <= TOL
+
+
 def test_long_frame_wide_and_narrow_chains_of_one_run(torch, oracle):
     """Three frames of 2^20 samples per job (the 60 s render's first run of frames): on 256 CUs the bus-fold pass
     takes tiles of 32 columns for the first two frames and of 16 columns, in a launch that starts at frame 2, for
