@@ -15,7 +15,7 @@ scaling) and the rank-local partial buses are combined by one RCCL reduce
 (wp_bus_reduce, called through the C ABI on a side stream with two bus buffers,
 so the reduce of step i overlaps the transforms of step i+1).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (≈6300 GB/s measured copy ceil
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)  # (the first three passes run 5-30 % slower: first touch of the workspace, clocks)
     ap.add_argument("--config", choices=["c3", "c5"], default="c3",
                     help="c3: 2 s stereo IR shared by all tracks (the configuration the metric is quoted on); "
                          "c5: per-GPU share of the 2048-track render, a 4 s IR per channel-job")
